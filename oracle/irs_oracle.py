@@ -1,0 +1,480 @@
+"""
+ORACLE -- TEST INFRASTRUCTURE ONLY.  Not shipped, not measured as the product.
+
+CPU (NumPy, float64) restatement of the iRS-LQR hot path of hjsuh94/irs_mpc.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module, and only as the checker / the reported CPU baseline.  The product
+(irs_mpc_amd) never imports it and fails loudly when its HIP library is absent.
+
+Every function cites the reference lines it follows (paths relative to the
+reference repo root).  Parity status: PINNED -- see tests/test_oracle_golden.py:
+  * rollout + cost + exact linearisation + TV-LQR + closed-loop forward pass are
+    pinned by the reference's own result files examples/pendulum/analysis/
+    pendulum_exact.csv and examples/quadrotor/analysis/quadrotor_exact.csv;
+  * dynamics / dynamics_batch / zero-order and first-order get_TV_matrices /
+    compute_least_squares / CEM local_descent are pinned by fixtures produced by
+    running the reference's own source in the build container
+    (tests/golden/make_fixtures.py, committed with its outputs).
+The QP solver itself (Drake + OSQP, irs_lqr/tv_lqr.py:69-137) is a third-party
+dependency that is not vendored and not installed; solve_tvlqr_qp() below
+restates the QP exactly as posed and solves its KKT system directly (valid while
+the box bounds are inactive), and the two *_exact.csv files anchor it.
+"""
+import numpy as np
+
+
+# --------------------------------------------------------------------------
+# Dynamics plugins (irs_lqr/dynamical_system.py:1-66 is the abstract surface)
+# --------------------------------------------------------------------------
+class PendulumOracle:
+    """examples/pendulum/pendulum_dynamics.py:8-127."""
+
+    name = "pendulum"
+
+    def __init__(self, h):
+        self.h = h
+        self.dim_x = 2
+        self.dim_u = 1
+
+    def dynamics(self, x, u):
+        # pendulum_dynamics.py:46-60, semi-implicit Euler
+        angle, speed = x[0], x[1]
+        next_speed = speed + self.h * (-np.sin(angle) + u[0])
+        next_angle = angle + self.h * next_speed
+        return np.array([next_angle, next_speed])
+
+    def dynamics_batch(self, x, u):
+        # pendulum_dynamics.py:62-81
+        angle, speed, torque = x[:, 0], x[:, 1], u[:, 0]
+        next_speed = speed + self.h * (-np.sin(angle) + torque)
+        next_angle = angle + self.h * next_speed
+        return np.vstack((next_angle, next_speed)).transpose()
+
+    def jacobian_xu(self, x, u):
+        # pendulum_dynamics.py:110-117 evaluates the symbolic Jacobian of
+        # dynamics_sym (:28-43); this is that Jacobian written out.
+        h, c = self.h, np.cos(x[0])
+        return np.array([[1.0 - h * h * c, h, h * h],
+                         [-h * c, 1.0, h]])
+
+    def jacobian_xu_batch(self, x, u):
+        # pendulum_dynamics.py:119-127
+        return np.stack([self.jacobian_xu(x[i], u[i]) for i in range(x.shape[0])])
+
+
+class QuadrotorOracle:
+    """examples/quadrotor/quadrotor_dynamics.py:15-231."""
+
+    name = "quadrotor"
+
+    def __init__(self, h):
+        self.h = h
+        self.dim_x = 12
+        self.dim_u = 4
+        self.m = 0.775
+        self.L = 0.15
+        self.g = 9.81
+        self.I = np.diag([0.0015, 0.0025, 0.0035])
+        self.I_inv = np.linalg.inv(self.I)
+        self.kF = 1.0
+        self.kM = 0.0245
+
+    # quadrotor_dynamics.py:150-186
+    @staticmethod
+    def _R_WB(rpy):
+        cr, sr = np.cos(rpy[0]), np.sin(rpy[0])
+        cp, sp = np.cos(rpy[1]), np.sin(rpy[1])
+        cy, sy = np.cos(rpy[2]), np.sin(rpy[2])
+        Rx = np.array([[1., 0., 0.], [0, cr, -sr], [0, sr, cr]], dtype=cr.dtype)
+        Ry = np.array([[cp, 0., sp], [0, 1., 0], [-sp, 0., cp]], dtype=cr.dtype)
+        Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0., 0., 1]], dtype=cr.dtype)
+        return Rz.dot(Ry.dot(Rx))
+
+    # quadrotor_dynamics.py:188-199
+    @staticmethod
+    def _PhiInv(rpy):
+        sr, cr = np.sin(rpy[0]), np.cos(rpy[0])
+        sp, cp = np.sin(rpy[1]), np.cos(rpy[1])
+        return np.array([[1, 0, -sp], [0, cr, sr * cp], [0, -sr, cr * cp]],
+                        dtype=sr.dtype)
+
+    # quadrotor_dynamics.py:201-212
+    @staticmethod
+    def _Phi(rpy):
+        sr, cr = np.sin(rpy[0]), np.cos(rpy[0])
+        sp, cp = np.sin(rpy[1]), np.cos(rpy[1])
+        return np.array([[1, sr * sp / cp, cr * sp / cp],
+                         [0, cr, -sr],
+                         [0, sr / cp, cr / cp]], dtype=sr.dtype)
+
+    # quadrotor_dynamics.py:215-231
+    @staticmethod
+    def _PhiD(rpy):
+        sr, cr = np.sin(rpy[0]), np.cos(rpy[0])
+        sp, cp = np.sin(rpy[1]), np.cos(rpy[1])
+        cp2 = cp ** 2
+        tp = sp / cp
+        D = np.zeros((3, 3, 3), dtype=sr.dtype)
+        D[0, 1] = [cr * tp, sr / cp2, 0]
+        D[0, 2] = [-sr * tp, cr / cp2, 0]
+        D[1, 1] = [-sr, 0, 0]
+        D[1, 2] = [-cr, 0, 0]
+        D[2, 1] = [cr / cp, sr * sp / cp2, 0]
+        D[2, 2] = [-sr / cp, cr * sp / cp2, 0]
+        return D
+
+    def dynamics(self, x, u):
+        # quadrotor_dynamics.py:40-77 (explicit Euler on an rpy rigid body)
+        x = np.asarray(x)
+        u = np.asarray(u)
+        dt = np.result_type(x.dtype, u.dtype, np.float64)
+        x = x.astype(dt)
+        u = u.astype(dt)
+        xdot = np.empty(x.shape, dtype=dt)
+        uF = self.kF * u
+        uM = self.kM * u
+        Fg = np.array([0., 0., -self.m * self.g])
+        F = np.array([0., 0., uF.sum()])
+        M = np.array([self.L * (-uF[0] - uF[1] + uF[2] + uF[3]),
+                      self.L * (-uF[0] - uF[3] + uF[1] + uF[2]),
+                      -uM[0] + uM[1] - uM[2] + uM[3]])
+        rpy = x[3:6]
+        rpy_d = x[9:12]
+        R_WB = self._R_WB(rpy)
+        xyz_dd = 1. / self.m * (R_WB.dot(F) + Fg)
+        pqr = self._PhiInv(rpy).dot(rpy_d)
+        pqr_d = self.I_inv.dot(M - np.cross(pqr, self.I.dot(pqr)))
+        Phi_d = self._PhiD(rpy)
+        Phi = self._Phi(rpy)
+        rpy_dd = Phi.dot(pqr_d) + (Phi_d.dot(rpy_d)).dot(pqr)
+        xdot[0:6] = x[6:12]
+        xdot[6:9] = xyz_dd
+        xdot[9:12] = rpy_dd
+        return x + self.h * xdot
+
+    def dynamics_batch(self, x, u):
+        # quadrotor_dynamics.py:79-91 (Python loop over the batch)
+        return np.stack([self.dynamics(x[b], u[b]) for b in range(x.shape[0])])
+
+    def jacobian_xu(self, x, u):
+        # quadrotor_dynamics.py:132-138: pydrake.forwarddiff.jacobian (forward-
+        # mode AD, i.e. the exact derivative) of dynamics_xu.  pydrake is not
+        # installed; the complex-step derivative of the same analytic map is
+        # exact to machine precision (no subtractive cancellation).
+        xu = np.hstack((x, u)).astype(np.complex128)
+        n, d = self.dim_x, self.dim_x + self.dim_u
+        J = np.zeros((n, d))
+        eps = 1e-30
+        for j in range(d):
+            z = xu.copy()
+            z[j] += 1j * eps
+            J[:, j] = self.dynamics(z[:n], z[n:]).imag / eps
+        return J
+
+    def jacobian_xu_batch(self, x, u):
+        # quadrotor_dynamics.py:140-148
+        return np.stack([self.jacobian_xu(x[i], u[i]) for i in range(x.shape[0])])
+
+
+SYSTEMS = {"pendulum": PendulumOracle, "quadrotor": QuadrotorOracle}
+
+
+# --------------------------------------------------------------------------
+# Trajectory helpers (irs_lqr/irs_lqr.py)
+# --------------------------------------------------------------------------
+def rollout(system, x0, u_trj):
+    """irs_lqr/irs_lqr.py:105-119."""
+    T = u_trj.shape[0]
+    x_trj = np.zeros((T + 1, system.dim_x))
+    x_trj[0] = x0
+    for t in range(T):
+        x_trj[t + 1] = system.dynamics(x_trj[t], u_trj[t])
+    return x_trj
+
+
+def evaluate_cost(x_trj, u_trj, xd_trj, Q, R):
+    """irs_lqr/irs_lqr.py:121-137.  NB the terminal term uses Q, not Qd (:135-136)."""
+    T = u_trj.shape[0]
+    cost = 0.0
+    for t in range(T):
+        et = x_trj[t] - xd_trj[t]
+        cost += et.dot(Q).dot(et)
+        cost += u_trj[t].dot(R).dot(u_trj[t])
+    et = x_trj[T] - xd_trj[T]
+    cost += et.dot(Q).dot(et)
+    return cost
+
+
+# --------------------------------------------------------------------------
+# Smoothed linearisations
+# --------------------------------------------------------------------------
+def compute_least_squares(dxdu, deltaf, dim_x, dim_u):
+    """irs_lqr/irs_lqr_zero_order.py:27-36 (SVD lstsq, no intercept)."""
+    ABhat = np.linalg.lstsq(dxdu, deltaf, rcond=None)[0].transpose()
+    return ABhat[:, :dim_x], ABhat[:, dim_x:dim_x + dim_u]
+
+
+def zero_order_TV(system, x_trj, u_trj, dx, du):
+    """irs_lqr/irs_lqr_zero_order.py:38-63 with the samples SUPPLIED:
+    dx (T,N,n), du (T,N,m) are what `sampling(x_t,u_t,iter)` returned at each t."""
+    T, n, m = u_trj.shape[0], system.dim_x, system.dim_u
+    At, Bt, ct = np.zeros((T, n, n)), np.zeros((T, n, m)), np.zeros((T, n))
+    for t in range(T):
+        fdt = system.dynamics_batch(x_trj[t] + dx[t], u_trj[t] + du[t])
+        ft = system.dynamics(x_trj[t], u_trj[t])
+        deltaf = fdt - ft
+        dxdu = np.hstack((dx[t], du[t]))
+        At[t], Bt[t] = compute_least_squares(dxdu, deltaf, n, m)
+        ct[t] = ft - At[t].dot(x_trj[t]) - Bt[t].dot(u_trj[t])
+    return At, Bt, ct
+
+
+def first_order_TV(system, x_trj, u_trj, dx, du):
+    """irs_lqr/irs_lqr_first_order.py:28-54 with the samples supplied."""
+    T, n, m = u_trj.shape[0], system.dim_x, system.dim_u
+    At, Bt, ct = np.zeros((T, n, n)), np.zeros((T, n, m)), np.zeros((T, n))
+    for t in range(T):
+        AB_batch = system.jacobian_xu_batch(x_trj[t] + dx[t], u_trj[t] + du[t])
+        ABhat = np.mean(AB_batch, axis=0)
+        At[t] = ABhat[:, :n]
+        Bt[t] = ABhat[:, n:n + m]
+        ct[t] = system.dynamics(x_trj[t], u_trj[t]) - At[t].dot(x_trj[t]) - Bt[t].dot(u_trj[t])
+    return At, Bt, ct
+
+
+def exact_TV(system, x_trj, u_trj):
+    """irs_lqr/irs_lqr_exact.py:15-31."""
+    T, n, m = u_trj.shape[0], system.dim_x, system.dim_u
+    At, Bt, ct = np.zeros((T, n, n)), np.zeros((T, n, m)), np.zeros((T, n))
+    for t in range(T):
+        AB = system.jacobian_xu(x_trj[t], u_trj[t])
+        At[t] = AB[:, :n]
+        Bt[t] = AB[:, n:n + m]
+        ct[t] = system.dynamics(x_trj[t], u_trj[t]) - At[t].dot(x_trj[t]) - Bt[t].dot(u_trj[t])
+    return At, Bt, ct
+
+
+def zero_order_B_fit(du, dx_next):
+    """irs_lqr/quasistatic_dynamics.py:242-266: B-only least squares on
+    u-perturbations (`np.linalg.lstsq(du, dx_next)[0].T`)."""
+    return np.linalg.lstsq(du, dx_next, rcond=None)[0].transpose()
+
+
+def gaussian_samples(T, N, std_x, std_u, it, power=0.5):
+    """The sampling closure of the example scripts, e.g.
+    examples/pendulum/pendulum_zero_order.py:38-43: per t, dx~N(0,std_x/iter^p)
+    (N,n) then du~N(0,std_u/iter^p) (N,m), drawn from the global legacy RNG."""
+    n, m = len(std_x), len(std_u)
+    dx = np.zeros((T, N, n))
+    du = np.zeros((T, N, m))
+    for t in range(T):
+        dx[t] = np.random.normal(0.0, np.asarray(std_x) / (it ** power), size=(N, n))
+        du[t] = np.random.normal(0.0, np.asarray(std_u) / (it ** power), size=(N, m))
+    return dx, du
+
+
+# --------------------------------------------------------------------------
+# TV-LQR
+# --------------------------------------------------------------------------
+def solve_tvlqr_qp(At, Bt, ct, Q, Qd, R, x0, x_trj_d):
+    """irs_lqr/tv_lqr.py:30-145 for indices_u_into_x=None and inactive bounds,
+    restated literally as the QP it poses and solved through its KKT system:
+
+      min  sum_t (x_t-xd_t)'Q(x_t-xd_t) + 1/2 u_t'R u_t  + (x_T-xd_T)'Qd(x_T-xd_T)
+      s.t. x_0 = x0 (:82),  A_t x_t + B_t u_t - x_{t+1} = -c_t (:87-90)
+
+    The 1/2 on R is Drake's AddQuadraticCost(Q,b,x) = 1/2 x'Qx + b'x (:110);
+    AddQuadraticErrorCost (:127,:130) is the full quadratic form."""
+    T = At.shape[0]
+    n, m = Q.shape[0], R.shape[0]
+    nz = (T + 1) * n + T * m
+    ix = lambda t: slice(t * n, (t + 1) * n)
+    iu = lambda t: slice((T + 1) * n + t * m, (T + 1) * n + (t + 1) * m)
+    H = np.zeros((nz, nz))      # objective = 1/2 z'Hz + g'z
+    g = np.zeros(nz)
+    for t in range(T):
+        H[ix(t), ix(t)] += 2.0 * Q
+        g[ix(t)] += -2.0 * Q.dot(x_trj_d[t])
+        H[iu(t), iu(t)] += R
+    H[ix(T), ix(T)] += 2.0 * Qd
+    g[ix(T)] += -2.0 * Qd.dot(x_trj_d[T])
+    ne = (T + 1) * n
+    E = np.zeros((ne, nz))
+    b = np.zeros(ne)
+    E[0:n, ix(0)] = np.eye(n)
+    b[0:n] = x0
+    for t in range(T):
+        r = slice((t + 1) * n, (t + 2) * n)
+        E[r, ix(t)] = At[t]
+        E[r, iu(t)] = Bt[t]
+        E[r, ix(t + 1)] = -np.eye(n)
+        b[r] = -ct[t]
+    KKT = np.block([[H, E.T], [E, np.zeros((ne, ne))]])
+    sol = np.linalg.solve(KKT, np.concatenate([-g, b]))
+    z = sol[:nz]
+    return z[:(T + 1) * n].reshape(T + 1, n), z[(T + 1) * n:].reshape(T, m)
+
+
+def tvlqr_riccati(At, Bt, ct, Q, Qd, R, x_trj_d, alpha_R=0.5):
+    """Backward Riccati pass for the QP of solve_tvlqr_qp (the gains the
+    reference never materialises).  Value function
+    V_t(x) = x'P_t x + 2 p_t'x + const, P_T=Qd, p_T=-Qd xd_T:
+        H = alpha_R R + B'PB,  K = -H^-1 B'PA,  k = -H^-1 B'(Pc+p)
+        P <- Q + A'P(A+BK),    p <- -Q xd_t + (A+BK)'(Pc+p)
+    Returns K (T,m,n), k (T,m)."""
+    T = At.shape[0]
+    n, m = Q.shape[0], R.shape[0]
+    K = np.zeros((T, m, n))
+    k = np.zeros((T, m))
+    P = Qd.copy()
+    p = -Qd.dot(x_trj_d[T])
+    for t in range(T - 1, -1, -1):
+        A, B, c = At[t], Bt[t], ct[t]
+        PB = P.dot(B)
+        H = alpha_R * R + B.T.dot(PB)
+        q = P.dot(c) + p
+        K[t] = -np.linalg.solve(H, PB.T.dot(A))
+        k[t] = -np.linalg.solve(H, B.T.dot(q))
+        Acl = A + B.dot(K[t])
+        P = Q + A.T.dot(P).dot(Acl)
+        P = 0.5 * (P + P.T)
+        p = -Q.dot(x_trj_d[t]) + Acl.T.dot(q)
+    return K, k
+
+
+def closed_loop_rollout(system, K, k, x0):
+    """irs_lqr/irs_lqr.py:169-184 with the re-solved QP's first control written
+    as the affine policy u_t = K_t x_t + k_t, and the TRUE dynamics (:184)."""
+    T, m, n = K.shape
+    x_new = np.zeros((T + 1, n))
+    u_new = np.zeros((T, m))
+    x_new[0] = x0
+    for t in range(T):
+        u_new[t] = K[t].dot(x_new[t]) + k[t]
+        x_new[t + 1] = system.dynamics(x_new[t], u_new[t])
+    return x_new, u_new
+
+
+def local_descent_qp(system, At, Bt, ct, Q, Qd, R, x0, xd_trj):
+    """irs_lqr/irs_lqr.py:148-186 literally: T tail re-solves, keep u*[0]."""
+    T = At.shape[0]
+    n, m = system.dim_x, system.dim_u
+    x_new = np.zeros((T + 1, n))
+    u_new = np.zeros((T, m))
+    x_new[0] = x0
+    for t in range(T):
+        _, u_star = solve_tvlqr_qp(At[t:T], Bt[t:T], ct[t:T], Q, Qd, R,
+                                   x_new[t], xd_trj[t:T + 1])
+        u_new[t] = u_star[0]
+        x_new[t + 1] = system.dynamics(x_new[t], u_new[t])
+    return x_new, u_new
+
+
+def local_descent(system, At, Bt, ct, Q, Qd, R, x0, xd_trj):
+    """Riccati form of local_descent_qp (identical result, O(T) instead of O(T^2))."""
+    K, k = tvlqr_riccati(At, Bt, ct, Q, Qd, R, xd_trj, alpha_R=0.5)
+    x_new, u_new = closed_loop_rollout(system, K, k, x0)
+    return x_new, u_new, K, k
+
+
+def iterate(system, Q, Qd, R, x0, xd_trj, u_trj_initial, max_iterations,
+            tv_fn):
+    """irs_lqr/irs_lqr.py:35-71 (ctor) + :188-218 (iterate).  `tv_fn(x_trj,
+    u_trj, iter) -> At,Bt,ct` is get_TV_matrices.  Performs max_iterations+1
+    descents; the last is logged but not adopted (:205-216)."""
+    u_trj = u_trj_initial
+    x_trj = rollout(system, x0, u_trj)
+    cost = evaluate_cost(x_trj, u_trj, xd_trj, Q, R)
+    cost_lst, x_lst, u_lst = [cost], [x_trj], [u_trj]
+    it = 1
+    while True:
+        At, Bt, ct = tv_fn(x_trj, u_trj, it)
+        x_new, u_new, _, _ = local_descent(system, At, Bt, ct, Q, Qd, R,
+                                           x_trj[0], xd_trj)
+        cost_new = evaluate_cost(x_new, u_new, xd_trj, Q, R)
+        x_lst.append(x_new)
+        u_lst.append(u_new)
+        cost_lst.append(cost_new)
+        if it > max_iterations:
+            break
+        cost, x_trj, u_trj = cost_new, x_new, u_new
+        it += 1
+    return x_trj, u_trj, cost, cost_lst, x_lst, u_lst
+
+
+# --------------------------------------------------------------------------
+# CEM baseline (irs_lqr/cem.py)
+# --------------------------------------------------------------------------
+def cem_local_descent(system, x0, u_trj, std_trj, xd_trj, Q, R, n_elite,
+                      u_trj_candidates):
+    """irs_lqr/cem.py:151-184 with the candidates supplied
+    (u_cand ~ N(u_trj, std_trj), shape (B,T,m), drawn at :159-161)."""
+    B = u_trj_candidates.shape[0]
+    cost_array = np.zeros(B)
+    for b in range(B):
+        cost_array[b] = evaluate_cost(rollout(system, x0, u_trj_candidates[b]),
+                                      u_trj_candidates[b], xd_trj, Q, R)
+    best_idx = np.argpartition(cost_array, n_elite)[:n_elite]
+    best = u_trj_candidates[best_idx]
+    u_new = np.mean(best, axis=0)
+    std_new = np.std(best, axis=0)
+    x_new = rollout(system, x0, u_new)
+    return x_new, u_new, std_new, cost_array
+
+
+# --------------------------------------------------------------------------
+# Device-RNG specification (mode G).  Not reference arithmetic: the reference
+# draws from NumPy's global MT19937 (e.g. pendulum_zero_order.py:38-43), which a
+# GPU cannot reproduce in parallel.  This restates the counter-based generator
+# the HIP library implements so its on-device samples can be checked exactly.
+# --------------------------------------------------------------------------
+_PHILOX_M0 = np.uint64(0xD2511F53)
+_PHILOX_M1 = np.uint64(0xCD9E8D57)
+_PHILOX_W0 = 0x9E3779B9
+_PHILOX_W1 = 0xBB67AE85
+
+
+def philox4x32_10(ctr, key):
+    """Philox4x32-10 (Salmon et al. 2011).  ctr: (...,4) uint32, key: (2,) ints."""
+    c = [ctr[..., i].astype(np.uint64) for i in range(4)]
+    k0, k1 = int(key[0]) & 0xFFFFFFFF, int(key[1]) & 0xFFFFFFFF
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = _PHILOX_M0 * c[0]
+        p1 = _PHILOX_M1 * c[2]
+        hi0, lo0 = p0 >> np.uint64(32), p0 & mask
+        hi1, lo1 = p1 >> np.uint64(32), p1 & mask
+        c = [hi1 ^ c[1] ^ np.uint64(k0), lo1, hi0 ^ c[3] ^ np.uint64(k1), lo0]
+        k0 = (k0 + _PHILOX_W0) & 0xFFFFFFFF
+        k1 = (k1 + _PHILOX_W1) & 0xFFFFFFFF
+    return np.stack([v.astype(np.uint32) for v in c], axis=-1)
+
+
+def device_gaussian_samples(T, N, n, m, std_x, std_u, seed, it,
+                            sample_offset=0, dtype=np.float64):
+    """Samples exactly as irs_mpc_amd/csrc draws them in mode G:
+    counter = (global sample index, t, block j, iter), key = (seed lo, seed hi);
+    each Philox call yields 4 uint32 -> 2 Box-Muller pairs -> 4 normals, which
+    fill components 4j..4j+3 of z=[dx|du]; component c is scaled by std[c]."""
+    d = n + m
+    nblk = (d + 3) // 4
+    std = np.concatenate([np.asarray(std_x, float), np.asarray(std_u, float)])
+    s_idx = (np.arange(N, dtype=np.uint64) + np.uint64(sample_offset))
+    z = np.zeros((T, N, nblk * 4))
+    key = (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    for t in range(T):
+        for j in range(nblk):
+            ctr = np.zeros((N, 4), dtype=np.uint32)
+            ctr[:, 0] = (s_idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+            ctr[:, 1] = t
+            ctr[:, 2] = j | ((s_idx >> np.uint64(32)).astype(np.uint32) << np.uint32(8))
+            ctr[:, 3] = it
+            r = philox4x32_10(ctr, key).astype(np.float64)
+            u = (r + 0.5) * (1.0 / 4294967296.0)        # (0,1)
+            for pair in range(2):
+                rad = np.sqrt(-2.0 * np.log(u[:, 2 * pair]))
+                ang = 2.0 * np.pi * u[:, 2 * pair + 1]
+                z[t, :, 4 * j + 2 * pair] = rad * np.cos(ang)
+                z[t, :, 4 * j + 2 * pair + 1] = rad * np.sin(ang)
+    z = z[:, :, :d] * std
+    return z[:, :, :n].astype(dtype), z[:, :, n:].astype(dtype)

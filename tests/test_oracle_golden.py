@@ -1,0 +1,216 @@
+"""Pins oracle/irs_oracle.py against (a) the reference's own result files and
+(b) fixtures produced by running the reference source (tests/golden/make_fixtures.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import irs_oracle as orc
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def pend_problem(T):
+    Q, Qd, R = np.diag([1., 1.]), np.diag([20., 20.]), np.diag([1.])
+    x0 = np.array([0., 0.])
+    xd = np.tile(np.array([np.pi, 0.]), (T + 1, 1))
+    u0 = np.tile(np.array([0.1]), (T, 1))
+    return Q, Qd, R, x0, xd, u0
+
+
+def quad_problem(T):
+    Q = np.diag([10., 10, 10, 10, 10, 10, 0, 0, 0, 0, 0, 0])
+    Qd = 10.0 * np.diag([10., 10, 10, 10, 10, 10, 1, 1, 1, 1, 1, 1])
+    R = np.eye(4)
+    x0 = np.zeros(12)
+    xd = np.zeros((T + 1, 12))
+    for i in range(T + 1):
+        xd[i, :3] = [1.5 * np.cos(0.05 * i), 1.5 * np.sin(0.05 * i), 0.02 * i]
+    u0 = np.tile(np.array([2.0, 2.0, 2.0, 2.0]), (T, 1))
+    return Q, Qd, R, x0, xd, u0
+
+
+# ---- (b) fixtures from the reference's own source -------------------------
+def test_pendulum_dynamics_fixture(golden_dir):
+    f = load(golden_dir, "pendulum_dynamics")
+    s = orc.PendulumOracle(float(f["h"]))
+    assert np.array_equal(s.dynamics_batch(f["X"], f["U"]), f["Xn"])
+    for i in range(f["X"].shape[0]):
+        assert np.array_equal(s.dynamics(f["X"][i], f["U"][i]), f["Xn_scalar"][i])
+
+
+def test_quadrotor_dynamics_fixture(golden_dir):
+    f = load(golden_dir, "quadrotor_dynamics")
+    s = orc.QuadrotorOracle(float(f["h"]))
+    np.testing.assert_allclose(s.dynamics_batch(f["X"], f["U"]), f["Xn"], rtol=0, atol=1e-13)
+
+
+def test_pendulum_rollout_cost_fixture(golden_dir):
+    f = load(golden_dir, "pendulum_T200_init")
+    Q, Qd, R, x0, xd, u0 = pend_problem(200)
+    s = orc.PendulumOracle(0.05)
+    x = orc.rollout(s, x0, u0)
+    assert np.array_equal(x, f["x_trj"])
+    assert orc.evaluate_cost(x, u0, xd, Q, R) == float(f["cost0"])
+
+
+def test_quadrotor_rollout_cost_fixture(golden_dir):
+    f = load(golden_dir, "quadrotor_T200_init")
+    Q, Qd, R, x0, xd, u0 = quad_problem(200)
+    s = orc.QuadrotorOracle(0.05)
+    x = orc.rollout(s, x0, u0)
+    np.testing.assert_allclose(x, f["x_trj"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(orc.evaluate_cost(x, u0, xd, Q, R), float(f["cost0"]), rtol=1e-13)
+
+
+@pytest.mark.parametrize("name,sysname", [("pendulum_zero_T30_N100", "pendulum"),
+                                          ("quadrotor_zero_T6_N64", "quadrotor")])
+def test_zero_order_fixture(golden_dir, name, sysname):
+    f = load(golden_dir, name)
+    s = orc.SYSTEMS[sysname](float(f["h"]))
+    At, Bt, ct = orc.zero_order_TV(s, f["x_trj"], f["u_trj"], f["dx"], f["du"])
+    np.testing.assert_allclose(At, f["At"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(Bt, f["Bt"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(ct, f["ct"], rtol=0, atol=1e-11)
+
+
+def test_zero_order_fixture_sampling_replay(golden_dir):
+    """np.random.seed + the script's sampling closure reproduces the recorded samples."""
+    f = load(golden_dir, "pendulum_zero_T30_N100")
+    np.random.seed(int(f["seed"]))
+    dx, du = orc.gaussian_samples(30, 100, [1.0, 1.0], [1.0], 1)
+    assert np.array_equal(dx, f["dx"]) and np.array_equal(du, f["du"])
+
+
+def test_first_order_fixture(golden_dir):
+    f = load(golden_dir, "pendulum_first_T30_N100")
+    s = orc.PendulumOracle(float(f["h"]))
+    At, Bt, ct = orc.first_order_TV(s, f["x_trj"], f["u_trj"], f["dx"], f["du"])
+    np.testing.assert_allclose(At, f["At"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(Bt, f["Bt"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(ct, f["ct"], rtol=0, atol=1e-13)
+
+
+def test_cem_fixture(golden_dir):
+    f = load(golden_dir, "pendulum_cem_T30_B50")
+    Q, Qd, R, x0, xd, _ = pend_problem(30)
+    s = orc.PendulumOracle(float(f["h"]))
+    x_new, u_new, std_new, _ = orc.cem_local_descent(
+        s, x0, f["u_trj"], f["std0"], xd, Q, R, int(f["n_elite"]), f["cand"])
+    np.testing.assert_allclose(u_new, f["u_new"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(std_new, f["std_new"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(x_new, f["x_new"], rtol=0, atol=1e-13)
+
+
+# ---- Jacobians: exact derivative vs central differences of the pinned dynamics
+@pytest.mark.parametrize("sysname", ["pendulum", "quadrotor"])
+def test_jacobian_vs_finite_difference(sysname):
+    s = orc.SYSTEMS[sysname](0.05)
+    rng = np.random.default_rng(5)
+    n, m = s.dim_x, s.dim_u
+    for _ in range(5):
+        x = rng.normal(size=n) * 0.4
+        u = 2.0 + rng.normal(size=m) * 0.4
+        J = s.jacobian_xu(x, u)
+        xu = np.hstack((x, u))
+        Jfd = np.zeros((n, n + m))
+        for j in range(n + m):
+            e = np.zeros(n + m)
+            e[j] = 1e-6
+            Jfd[:, j] = (s.dynamics((xu + e)[:n], (xu + e)[n:]) -
+                         s.dynamics((xu - e)[:n], (xu - e)[n:])) / 2e-6
+        np.testing.assert_allclose(J, Jfd, rtol=0, atol=2e-8)
+
+
+# ---- Riccati form == literal QP re-solves (irs_lqr.py:169-184) -------------
+@pytest.mark.parametrize("sysname,T", [("pendulum", 12), ("quadrotor", 6)])
+def test_riccati_equals_qp_resolves(sysname, T):
+    s = orc.SYSTEMS[sysname](0.05)
+    Q, Qd, R, x0, xd, u0 = (pend_problem if sysname == "pendulum" else quad_problem)(T)
+    x = orc.rollout(s, x0, u0)
+    At, Bt, ct = orc.exact_TV(s, x, u0)
+    xq, uq = orc.local_descent_qp(s, At, Bt, ct, Q, Qd, R, x0, xd)
+    xr, ur, K, k = orc.local_descent(s, At, Bt, ct, Q, Qd, R, x0, xd)
+    np.testing.assert_allclose(ur, uq, rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(xr, xq, rtol=1e-7, atol=1e-8)
+    # open-loop QP solution from t=0 == linear-model rollout of the policy
+    xs, us = orc.solve_tvlqr_qp(At, Bt, ct, Q, Qd, R, x0, xd)
+    xl = x0.copy()
+    for t in range(T):
+        ul = K[t].dot(xl) + k[t]
+        np.testing.assert_allclose(ul, us[t], rtol=1e-6, atol=1e-7)
+        xl = At[t].dot(xl) + Bt[t].dot(ul) + ct[t]
+
+
+# ---- (a) the reference's own result files ---------------------------------
+def test_pendulum_exact_csv(golden_dir):
+    """examples/pendulum/pendulum_exact.py (T=200, iterate(10) logs costs) vs
+    examples/pendulum/analysis/pendulum_exact.csv."""
+    gold = np.loadtxt(os.path.join(golden_dir, "pendulum_exact.csv"))
+    Q, Qd, R, x0, xd, u0 = pend_problem(200)
+    s = orc.PendulumOracle(0.05)
+    tv = lambda x, u, it: orc.exact_TV(s, x, u)
+    *_, cost_lst, _, _ = orc.iterate(s, Q, Qd, R, x0, xd, u0, len(gold) - 2, tv)
+    np.testing.assert_allclose(cost_lst, gold, rtol=2e-9)
+
+
+def test_quadrotor_exact_csv(golden_dir):
+    """examples/quadrotor/quadrotor_exact.py vs analysis/quadrotor_exact.csv.
+    Entries 0-4: the rpy box (quadrotor_first_order.py:29-34) is inactive there."""
+    gold = np.loadtxt(os.path.join(golden_dir, "quadrotor_exact.csv"))[:5]
+    Q, Qd, R, x0, xd, u0 = quad_problem(200)
+    s = orc.QuadrotorOracle(0.05)
+    tv = lambda x, u, it: orc.exact_TV(s, x, u)
+    *_, cost_lst, x_lst, _ = orc.iterate(s, Q, Qd, R, x0, xd, u0, 3, tv)
+    np.testing.assert_allclose(cost_lst, gold, rtol=1e-7)
+    assert max(np.abs(x[:, 4]).max() for x in x_lst) < np.pi / 2
+
+
+def test_alpha_R_one_does_not_match(golden_dir):
+    """Guards the Drake 1/2-R convention (tv_lqr.py:110): full-weight R misses."""
+    gold = np.loadtxt(os.path.join(golden_dir, "pendulum_exact.csv"))
+    Q, Qd, R, x0, xd, u0 = pend_problem(200)
+    s = orc.PendulumOracle(0.05)
+    x = orc.rollout(s, x0, u0)
+    At, Bt, ct = orc.exact_TV(s, x, u0)
+    K, k = orc.tvlqr_riccati(At, Bt, ct, Q, Qd, R, xd, alpha_R=1.0)
+    xn, un = orc.closed_loop_rollout(s, K, k, x0)
+    assert abs(orc.evaluate_cost(xn, un, xd, Q, R) - gold[1]) > 10.0
+
+
+def test_stochastic_band(golden_dir):
+    """Zero-order N=1000 iteration-1 cost lands in the band of the reference's
+    own two unseeded runs (943.04 / 944.37), SURVEY 4."""
+    gold = np.loadtxt(os.path.join(golden_dir, "pendulum_zero_order.csv"))
+    Q, Qd, R, x0, xd, u0 = pend_problem(200)
+    s = orc.PendulumOracle(0.05)
+    np.random.seed(11)
+    x = orc.rollout(s, x0, u0)
+    dx, du = orc.gaussian_samples(200, 1000, [1., 1.], [1.], 1)
+    At, Bt, ct = orc.zero_order_TV(s, x, u0, dx, du)
+    xn, un, _, _ = orc.local_descent(s, At, Bt, ct, Q, Qd, R, x0, xd)
+    c1 = orc.evaluate_cost(xn, un, xd, Q, R)
+    assert abs(c1 - gold[1]) / gold[1] < 0.01
+
+
+# ---- device RNG spec ------------------------------------------------------
+def test_philox_known_answer():
+    """Random123 kat_vectors: philox4x32-10."""
+    z = orc.philox4x32_10(np.zeros((1, 4), np.uint32), (0, 0))[0]
+    assert [hex(v) for v in z] == ['0x6627e8d5', '0xe169c58d', '0xbc57ac4c', '0x9b00dbd8']
+    f = np.full((1, 4), 0xFFFFFFFF, np.uint32)
+    z = orc.philox4x32_10(f, (0xFFFFFFFF, 0xFFFFFFFF))[0]
+    assert [hex(v) for v in z] == ['0x408f276d', '0x41c83b0e', '0xa20bc7c6', '0x6d5451fd']
+    c = np.array([[0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344]], np.uint32)
+    z = orc.philox4x32_10(c, (0xa4093822, 0x299f31d0))[0]
+    assert [hex(v) for v in z] == ['0xd16cfe09', '0x94fdcceb', '0x5001e420', '0x24126ea1']
+
+
+def test_device_gaussian_moments():
+    dx, du = orc.device_gaussian_samples(2, 20000, 2, 1, [1.0, 0.5], [2.0], seed=7, it=1)
+    z = np.concatenate([dx, du], axis=2).reshape(-1, 3)
+    assert np.abs(z.mean(0)).max() < 0.02
+    np.testing.assert_allclose(z.std(0), [1.0, 0.5, 2.0], rtol=0.02)
+    assert np.abs(np.corrcoef(z.T) - np.eye(3)).max() < 0.02
