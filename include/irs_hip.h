@@ -1,0 +1,180 @@
+/*
+ * irs_hip.h -- C ABI of libirs_hip.so, the MI355X (gfx950) implementation of the
+ * iRS-LQR inner loop of hjsuh94/irs_mpc.
+ *
+ * The reference has no FFI: its hot path is Python calling NumPy / Drake.  Each
+ * entry point below names the reference interface (file:line, relative to the
+ * reference repo root) it replaces; INTEGRATION.md shows the ctypes stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *  - Plain C: pointers and sizes only.  No allocation, no retained pointers, no
+ *    host synchronisation inside any call: every call enqueues kernels on
+ *    `stream` (a hipStream_t passed as void*; NULL = the default stream) and
+ *    returns.  All calls are hipGraph-capturable.
+ *  - Pointers marked DEV are device (HBM) pointers owned by the caller; pointers
+ *    marked HOST are read during the call and not retained.
+ *  - All matrices are C-contiguous row-major.  Trajectories, matrices, gains and
+ *    costs are float64 (the reference computes in float64); the sample tensors
+ *    dx/du, which carry all the bytes, are float32 and the per-sample dynamics
+ *    evaluation runs in float32 (`dtype` of the path: f32).
+ *  - Return value: IRS_OK (0) or a negative irs_status; irs_last_error() returns
+ *    a thread-local message.  Numerical failures inside kernels (non-SPD Gram or
+ *    Hessian) are reported through the DEV `info` arrays, LAPACK style.
+ *  - `params` HOST: model constants, params[0] = h (step size); see irs_model_info.
+ */
+#ifndef IRS_HIP_H
+#define IRS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IRS_ABI_VERSION 1
+
+typedef enum irs_status {
+    IRS_OK = 0,
+    IRS_ERR_INVALID_ARG = -1,
+    IRS_ERR_HIP = -2,
+    IRS_ERR_UNSUPPORTED = -3,
+    IRS_ERR_WORKSPACE = -4
+} irs_status;
+
+/* Device models = the reference's DynamicalSystem plugins that exist as device
+ * functors (irs_lqr/dynamical_system.py:1-66).                                  */
+typedef enum irs_model_id {
+    IRS_MODEL_PENDULUM = 0,   /* examples/pendulum/pendulum_dynamics.py:8-127; params = {h}            */
+    IRS_MODEL_QUADROTOR = 1   /* examples/quadrotor/quadrotor_dynamics.py:15-231;
+                                 params = {h, m, L, g, Ixx, Iyy, Izz, kF, kM}                          */
+} irs_model_id;
+
+/* Smoothing estimators.                                                         */
+typedef enum irs_smooth_mode {
+    IRS_SMOOTH_ZERO_ORDER_AB = 0, /* irs_lqr/irs_lqr_zero_order.py:38-63 (LSQ fit through N one-step evals) */
+    IRS_SMOOTH_FIRST_ORDER = 1,   /* irs_lqr/irs_lqr_first_order.py:28-54 (mean of N sampled Jacobians)     */
+    IRS_SMOOTH_ZERO_ORDER_B = 2   /* irs_lqr/quasistatic_dynamics.py:242-266 (u-only noise: B by LSQ,
+                                     A = exact Jacobian at the nominal point)                               */
+} irs_smooth_mode;
+
+int irs_abi_version(void);
+const char *irs_last_error(void);
+
+/* dim_x, dim_u and the number of model constants (`h, dim_x, dim_u` attributes of
+ * irs_lqr/dynamical_system.py:8-10).                                             */
+int irs_model_info(int model, int *dim_x, int *dim_u, int *n_params);
+
+/* ---- DynamicalSystem plugin surface (irs_lqr/dynamical_system.py:12-66) ------ */
+
+/* dynamics_batch (:24-38): Xn[b] = f(X[b], U[b]).  X (B,n), U (B,m), Xn (B,n) DEV f64. */
+int irs_dynamics_batch(int model, const double *params, int n_params,
+                       const double *X, const double *U, int B, double *Xn, void *stream);
+
+/* jacobian_xu_batch (:53-66): J[b] = df/d[x,u] at (X[b],U[b]); J (B,n,n+m) DEV f64.
+ * Forward-mode AD of the device functor, like the reference's forwarddiff/symbolic
+ * Jacobians (quadrotor_dynamics.py:136-148, pendulum_dynamics.py:110-127).        */
+int irs_jacobian_xu_batch(int model, const double *params, int n_params,
+                          const double *X, const double *U, int B, double *J, void *stream);
+
+/* IrsLqr.rollout + evaluate_cost (irs_lqr/irs_lqr.py:105-119, :121-137).
+ * x0 (n), u_trj (T,m), Q (n,n), R (m,m), xd_trj (T+1,n) DEV f64 in;
+ * x_trj (T+1,n), cost (1) DEV f64 out.  Terminal term uses Q (reference :135-136). */
+int irs_rollout_cost(int model, const double *params, int n_params, int T,
+                     const double *x0, const double *u_trj, const double *Q,
+                     const double *R, const double *xd_trj, double *x_trj,
+                     double *cost, void *stream);
+
+/* IrsLqr.evaluate_cost (irs_lqr/irs_lqr.py:121-137) of a GIVEN (x_trj, u_trj) pair:
+ * sum_t (x_t-xd_t)'Q(x_t-xd_t) + u_t'R u_t  +  (x_T-xd_T)'Q(x_T-xd_T).  Any n<=32, m<=16. */
+int irs_evaluate_cost(int n, int m, int T, const double *x_trj, const double *u_trj,
+                      const double *Q, const double *R, const double *xd_trj,
+                      double *cost, void *stream);
+
+/* ---- Randomised-smoothing linearisation (get_TV_matrices) -------------------- */
+
+/* Length P of one timestep's sufficient statistics:
+ *   ZERO_ORDER_AB: d(d+1)/2 (upper Gram of z=[dx,du]) + d*n (z (f(x+dx,u+du)-f(x,u))')
+ *   FIRST_ORDER  : n*d      (sum of Jacobians)
+ *   ZERO_ORDER_B : m(m+1)/2 + m*n                                  (d = n+m)      */
+int irs_sums_len(int model, int mode);
+
+/* Bytes of DEV scratch irs_smooth_accumulate* needs for (T, N).                  */
+size_t irs_smooth_workspace_bytes(int model, int mode, int T, int N);
+
+/* Sample pass, samples SUPPLIED (parity mode; "identical seeds" = the host draws
+ * them exactly as the reference's `sampling(x_t,u_t,iter)` closure does, e.g.
+ * examples/pendulum/pendulum_zero_order.py:38-43).
+ *   x_trj (T+1,n), u_trj (T,m) DEV f64; dx (T,N,n), du (T,N,m) DEV f32
+ *   (dx may be NULL for ZERO_ORDER_B); sums (T,P) DEV f64 out.
+ * N is the number of samples per timestep held by THIS device; sums of several
+ * devices add (one all-reduce of `sums` replaces zmq_parallel_cmp/array_io.py:6-26). */
+int irs_smooth_accumulate(int model, const double *params, int n_params, int mode,
+                          int T, int N, const double *x_trj, const double *u_trj,
+                          const float *dx, const float *du, double *sums,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+/* Sample pass with on-device Philox4x32-10 + Box-Muller draws (throughput mode):
+ * z_c ~ N(0, std_c), std = [std_x | std_u] HOST (n+m); the stream is a pure function
+ * of (seed, iter, t, sample_offset + i), so results do not depend on how samples
+ * are split over devices.  Specification: oracle/irs_oracle.py:device_gaussian_samples. */
+int irs_smooth_accumulate_rng(int model, const double *params, int n_params, int mode,
+                              int T, int N, const double *x_trj, const double *u_trj,
+                              const double *std_x, const double *std_u, uint64_t seed,
+                              uint32_t iter, uint64_t sample_offset, double *sums,
+                              void *workspace, size_t workspace_bytes, void *stream);
+
+/* Debug/verification: writes the samples irs_smooth_accumulate_rng would draw.   */
+int irs_rng_samples(int n, int m, int T, int N, const double *std_x, const double *std_u,
+                    uint64_t seed, uint32_t iter, uint64_t sample_offset,
+                    float *dx, float *du, void *stream);
+
+/* Solve: sums (T,P) -> At (T,n,n), Bt (T,n,m), ct (T,n) DEV f64,
+ * c_t = f(x_t,u_t) - A_t x_t - B_t u_t (irs_lqr_zero_order.py:59-62).
+ * N_total = samples per timestep summed over all devices.
+ * info (T) DEV int32: 0 ok, j>0 = Gram matrix not positive definite at pivot j.
+ * ZERO_ORDER_AB solves the normal equations of compute_least_squares
+ * (irs_lqr_zero_order.py:27-36) by Jacobi-scaled Cholesky in f64.                */
+int irs_smooth_finalize(int model, const double *params, int n_params, int mode,
+                        int T, long long N_total, const double *x_trj, const double *u_trj,
+                        const double *sums, double *At, double *Bt, double *ct,
+                        int *info, void *stream);
+
+/* IrsLqrExact.get_TV_matrices (irs_lqr/irs_lqr_exact.py:15-31).                  */
+int irs_exact_linearize(int model, const double *params, int n_params, int T,
+                        const double *x_trj, const double *u_trj,
+                        double *At, double *Bt, double *ct, void *stream);
+
+/* ---- TV-LQR (irs_lqr/tv_lqr.py:30-145, bounds inactive) ---------------------- */
+
+/* Backward Riccati pass of the QP solve_tvlqr poses:
+ *   min sum_t (x_t-xd_t)'Q(x_t-xd_t) + alpha_R u_t'R u_t + (x_T-xd_T)'Qd(x_T-xd_T)
+ *   s.t. x_{t+1} = A_t x_t + B_t u_t + c_t
+ * alpha_R = 0.5 reproduces Drake's AddQuadraticCost (tv_lqr.py:110).
+ * Any n <= 32, m <= 16.  K (T,m,n), k (T,m) DEV f64 out: u_t = K_t x_t + k_t.
+ * info (1) DEV int32: 0 ok, t+1 = Hessian not positive definite at step t.       */
+int irs_tvlqr_riccati(int n, int m, int T, const double *At, const double *Bt,
+                      const double *ct, const double *Q, const double *Qd,
+                      const double *R, double alpha_R, const double *xd_trj,
+                      double *K, double *k, int *info, void *stream);
+
+/* solve_tvlqr's return value (x*, u*): the policy rolled out on the LINEAR model
+ * from x0.  x_star (T+1,n), u_star (T,m) DEV f64 out.                            */
+int irs_tvlqr_linear_rollout(int n, int m, int T, const double *At, const double *Bt,
+                             const double *ct, const double *K, const double *k,
+                             const double *x0, double *x_star, double *u_star,
+                             void *stream);
+
+/* The forward loop of IrsLqr.local_descent (irs_lqr/irs_lqr.py:169-184): u_t =
+ * K_t x_t + k_t (== the re-solved QP's first control), x_{t+1} = f(x_t,u_t) on the
+ * TRUE dynamics, plus evaluate_cost of the result.                                */
+int irs_closed_loop_rollout(int model, const double *params, int n_params, int T,
+                            const double *K, const double *k, const double *x0,
+                            const double *Q, const double *R, const double *xd_trj,
+                            double *x_new, double *u_new, double *cost, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IRS_HIP_H */

@@ -1,0 +1,8 @@
+"""irs_mpc_amd -- MI355X-native iRS-LQR inner loop (drop-in for the smoothing +
+TV-LQR hot path of hjsuh94/irs_mpc).  See DESIGN.md."""
+from .dynamical_system import DynamicalSystem                       # noqa: F401
+from .irs_lqr import (IrsLqr, IrsLqrExact, IrsLqrFirstOrder,        # noqa: F401
+                      IrsLqrParameters, IrsLqrZeroOrder)
+from .sampling import GaussianSmoothing                             # noqa: F401
+from .systems import PendulumDynamics, QuadrotorDynamics            # noqa: F401
+from .tv_lqr import get_solver, solve_tvlqr                         # noqa: F401

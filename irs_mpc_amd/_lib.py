@@ -1,0 +1,87 @@
+"""ctypes binding of libirs_hip.so (include/irs_hip.h).
+
+There is NO fallback: if the HIP library has not been built, or a call fails,
+this module raises.  Nothing under oracle/ is ever imported from here.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, c_char_p, c_double, c_int, c_longlong, c_size_t,
+                    c_uint32, c_uint64, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libirs_hip.so")
+
+IRS_OK = 0
+MODEL_PENDULUM = 0
+MODEL_QUADROTOR = 1
+SMOOTH_ZERO_ORDER_AB = 0
+SMOOTH_FIRST_ORDER = 1
+SMOOTH_ZERO_ORDER_B = 2
+
+_dp = c_void_p   # device pointers travel as plain addresses
+
+# name -> (restype, argtypes); must list every symbol declared in include/irs_hip.h
+SIGNATURES = {
+    "irs_abi_version": (c_int, []),
+    "irs_last_error": (c_char_p, []),
+    "irs_model_info": (c_int, [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "irs_dynamics_batch": (c_int, [c_int, POINTER(c_double), c_int, _dp, _dp, c_int, _dp, c_void_p]),
+    "irs_jacobian_xu_batch": (c_int, [c_int, POINTER(c_double), c_int, _dp, _dp, c_int, _dp, c_void_p]),
+    "irs_rollout_cost": (c_int, [c_int, POINTER(c_double), c_int, c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, c_void_p]),
+    "irs_evaluate_cost": (c_int, [c_int, c_int, c_int, _dp, _dp, _dp, _dp, _dp, _dp, c_void_p]),
+    "irs_sums_len": (c_int, [c_int, c_int]),
+    "irs_smooth_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "irs_smooth_accumulate": (c_int, [c_int, POINTER(c_double), c_int, c_int, c_int, c_int, _dp, _dp,
+                                      _dp, _dp, _dp, _dp, c_size_t, c_void_p]),
+    "irs_smooth_accumulate_rng": (c_int, [c_int, POINTER(c_double), c_int, c_int, c_int, c_int, _dp, _dp,
+                                          POINTER(c_double), POINTER(c_double), c_uint64, c_uint32,
+                                          c_uint64, _dp, _dp, c_size_t, c_void_p]),
+    "irs_rng_samples": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_double), POINTER(c_double),
+                                c_uint64, c_uint32, c_uint64, _dp, _dp, c_void_p]),
+    "irs_smooth_finalize": (c_int, [c_int, POINTER(c_double), c_int, c_int, c_int, c_longlong, _dp, _dp,
+                                    _dp, _dp, _dp, _dp, _dp, c_void_p]),
+    "irs_exact_linearize": (c_int, [c_int, POINTER(c_double), c_int, c_int, _dp, _dp, _dp, _dp, _dp, c_void_p]),
+    "irs_tvlqr_riccati": (c_int, [c_int, c_int, c_int, _dp, _dp, _dp, _dp, _dp, _dp, c_double, _dp,
+                                  _dp, _dp, _dp, c_void_p]),
+    "irs_tvlqr_linear_rollout": (c_int, [c_int, c_int, c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, c_void_p]),
+    "irs_closed_loop_rollout": (c_int, [c_int, POINTER(c_double), c_int, c_int, _dp, _dp, _dp, _dp, _dp,
+                                        _dp, _dp, _dp, _dp, c_void_p]),
+}
+
+_lib = None
+
+
+class IrsHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads libirs_hip.so (once).  Raises ImportError if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "irs_mpc_amd: %s not found. Build it with `make -C irs_mpc_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.irs_abi_version() != 1:
+        raise ImportError("irs_mpc_amd: ABI version mismatch in %s" % LIB_PATH)
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != IRS_OK:
+        msg = load().irs_last_error().decode("utf-8", "replace")
+        raise IrsHipError("%s failed (status %d): %s" % (what, rc, msg))
+
+
+def dbl_array(values):
+    arr = (c_double * len(values))(*[float(v) for v in values])
+    return arr

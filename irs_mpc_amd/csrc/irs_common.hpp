@@ -1,0 +1,52 @@
+// Shared host-side helpers for the C ABI implementation files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include "../../include/irs_hip.h"
+#include "models.hpp"
+
+void irs_set_error(const char* fmt, ...);
+
+#define IRS_CHECK_ARG(cond, msg)                               \
+    do {                                                       \
+        if (!(cond)) {                                         \
+            irs_set_error("%s: %s", __func__, msg);            \
+            return IRS_ERR_INVALID_ARG;                        \
+        }                                                      \
+    } while (0)
+
+#define IRS_CHECK_LAUNCH()                                                   \
+    do {                                                                     \
+        hipError_t e_ = hipGetLastError();                                   \
+        if (e_ != hipSuccess) {                                              \
+            irs_set_error("%s: HIP error %s", __func__, hipGetErrorString(e_)); \
+            return IRS_ERR_HIP;                                              \
+        }                                                                    \
+    } while (0)
+
+// Expands BODY once per registered model with `Model` bound to its functor type.
+#define IRS_DISPATCH_MODEL(model_id, ...)                                       \
+    switch (model_id) {                                                           \
+        case IRS_MODEL_PENDULUM: { using Model = PendulumModel; __VA_ARGS__; } break;    \
+        case IRS_MODEL_QUADROTOR: { using Model = QuadrotorModel; __VA_ARGS__; } break;  \
+        default:                                                                  \
+            irs_set_error("%s: unknown model id %d", __func__, (int)(model_id));  \
+            return IRS_ERR_UNSUPPORTED;                                           \
+    }
+
+static inline int irs_load_params(int model, const double* params, int n_params, ModelParams* out) {
+    int need = -1;
+    switch (model) {
+        case IRS_MODEL_PENDULUM: need = PendulumModel::NPARAMS; break;
+        case IRS_MODEL_QUADROTOR: need = QuadrotorModel::NPARAMS; break;
+        default: irs_set_error("unknown model id %d", model); return IRS_ERR_UNSUPPORTED;
+    }
+    if (params == nullptr || n_params != need) {
+        irs_set_error("model %d expects %d params, got %d", model, need, n_params);
+        return IRS_ERR_INVALID_ARG;
+    }
+    memset(out, 0, sizeof(*out));
+    for (int i = 0; i < need; ++i) out->v[i] = params[i];
+    return IRS_OK;
+}

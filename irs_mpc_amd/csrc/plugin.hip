@@ -1,0 +1,93 @@
+// Device-side DynamicalSystem plugin surface (irs_lqr/dynamical_system.py:12-66):
+// dynamics_batch and jacobian_xu_batch in float64, one lane per batch element.
+// Also owns the library-wide error string and model registry queries.
+#include <cstdarg>
+#include "irs_common.hpp"
+
+static thread_local char g_err[512] = "";
+
+void irs_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+namespace {
+
+template <class Model>
+__global__ void dynamics_batch_kernel(ModelParams p, const double* X, const double* U, int B, double* Xn) {
+    constexpr int n = Model::NX, m = Model::NU;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double x[n], u[m], xn[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) x[i] = X[(size_t)b * n + i];
+#pragma unroll
+    for (int j = 0; j < m; ++j) u[j] = U[(size_t)b * m + j];
+    Model::template step<double>(p, x, u, xn);
+#pragma unroll
+    for (int i = 0; i < n; ++i) Xn[(size_t)b * n + i] = xn[i];
+}
+
+template <class Model>
+__global__ __launch_bounds__(64) void jacobian_batch_kernel(ModelParams p, const double* X, const double* U, int B, double* J) {
+    constexpr int n = Model::NX, m = Model::NU, d = n + m;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double x[n], u[m], xn[n], Jl[n * d];
+#pragma unroll
+    for (int i = 0; i < n; ++i) x[i] = X[(size_t)b * n + i];
+#pragma unroll
+    for (int j = 0; j < m; ++j) u[j] = U[(size_t)b * m + j];
+    model_jacobian<Model, double>(p, x, u, xn, Jl);
+#pragma unroll
+    for (int q = 0; q < n * d; ++q) J[(size_t)b * n * d + q] = Jl[q];
+}
+
+}  // namespace
+
+extern "C" {
+
+int irs_abi_version(void) { return IRS_ABI_VERSION; }
+
+const char* irs_last_error(void) { return g_err; }
+
+int irs_model_info(int model, int* dim_x, int* dim_u, int* n_params) {
+    IRS_DISPATCH_MODEL(model, {
+        if (dim_x) *dim_x = Model::NX;
+        if (dim_u) *dim_u = Model::NU;
+        if (n_params) *n_params = Model::NPARAMS;
+    });
+    return IRS_OK;
+}
+
+int irs_dynamics_batch(int model, const double* params, int n_params, const double* X,
+                       const double* U, int B, double* Xn, void* stream) {
+    IRS_CHECK_ARG(B > 0 && X && U && Xn, "bad argument");
+    ModelParams p;
+    int rc = irs_load_params(model, params, n_params, &p);
+    if (rc != IRS_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    IRS_DISPATCH_MODEL(model, {
+        hipLaunchKernelGGL((dynamics_batch_kernel<Model>), dim3((B + 255) / 256), dim3(256), 0, st, p, X, U, B, Xn);
+    });
+    IRS_CHECK_LAUNCH();
+    return IRS_OK;
+}
+
+int irs_jacobian_xu_batch(int model, const double* params, int n_params, const double* X,
+                          const double* U, int B, double* J, void* stream) {
+    IRS_CHECK_ARG(B > 0 && X && U && J, "bad argument");
+    ModelParams p;
+    int rc = irs_load_params(model, params, n_params, &p);
+    if (rc != IRS_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    IRS_DISPATCH_MODEL(model, {
+        hipLaunchKernelGGL((jacobian_batch_kernel<Model>), dim3((B + 63) / 64), dim3(64), 0, st, p, X, U, B, J);
+    });
+    IRS_CHECK_LAUNCH();
+    return IRS_OK;
+}
+
+}  // extern "C"

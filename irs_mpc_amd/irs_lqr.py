@@ -1,0 +1,261 @@
+"""Host mirror of the reference optimizers, driving the HIP library.
+
+    IrsLqrParameters, IrsLqr            irs_lqr/irs_lqr.py:7-31, :34-218
+    IrsLqrZeroOrder                     irs_lqr/irs_lqr_zero_order.py:5-63
+    IrsLqrFirstOrder                    irs_lqr/irs_lqr_first_order.py:6-54
+    IrsLqrExact                         irs_lqr/irs_lqr_exact.py:6-31
+
+Same constructor signatures, attributes (`x_trj, u_trj, cost, iter, T, x_trj_lst,
+u_trj_lst, cost_lst`), methods and error behaviour, so the example scripts run with
+only their import root changed.  What differs underneath: one iteration is a handful
+of kernel launches (sample pass -> solve -> Riccati -> closed-loop rollout) with the
+trajectories resident in HBM; NumPy arrays appear only at the public boundary.
+
+`sampling` may be
+  * a Python callable `dx, du = sampling(x_t, u_t, iter)` as in the reference: the
+    host draws (identical seeds => identical samples), the device evaluates;
+  * a `GaussianSmoothing`: samples are drawn on the device (Philox).
+With torch.distributed initialised (world_size > 1) the N samples of every timestep
+are sharded over the ranks and the per-timestep sums are all-reduced once per
+iteration (replaces zmq_parallel_cmp/array_io.py + the worker processes).
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import device as dev
+from . import distributed as dist_util
+from ._lib import SMOOTH_FIRST_ORDER, SMOOTH_ZERO_ORDER_AB
+from .sampling import GaussianSmoothing
+from .tv_lqr import get_solver
+
+
+class IrsLqrParameters:
+    """irs_lqr/irs_lqr.py:7-31."""
+
+    def __init__(self):
+        self.Q = None
+        self.Qd = None
+        self.R = None
+        self.x0 = None
+        self.xd_trj = None
+        self.u_trj_initial = None
+        self.xbound = None
+        self.ubound = None
+        self.solver_name = "osqp"
+
+
+class IrsLqr:
+    def __init__(self, system, params):
+        self.system = system
+        self.params = params
+        self.check_valid_system(self.system)
+        self.check_valid_params(self.params, self.system)
+
+        self.Q = params.Q
+        self.Qd = params.Qd
+        self.R = params.R
+        self.x0 = params.x0
+        self.xd_trj = params.xd_trj
+        self.u_trj = params.u_trj_initial
+        self.xbound = params.xbound
+        self.ubound = params.ubound
+        self.solver = get_solver(params.solver_name)
+
+        self.T = self.u_trj.shape[0]
+        self.dim_x = self.system.dim_x
+        self.dim_u = self.system.dim_u
+
+        # device-resident problem data (f64)
+        self._dm = system.dm()
+        self._Q = dev.to_dev(np.asarray(self.Q, float))
+        self._Qd = dev.to_dev(np.asarray(self.Qd, float))
+        self._R = dev.to_dev(np.asarray(self.R, float))
+        self._x0 = dev.to_dev(np.asarray(self.x0, float))
+        self._xd = dev.to_dev(np.asarray(self.xd_trj, float))
+
+        self.x_trj = self.rollout(self.x0, self.u_trj)
+        self.cost = self.evaluate_cost(self.x_trj, self.u_trj)
+
+        self.x_trj_lst = [self.x_trj]
+        self.u_trj_lst = [self.u_trj]
+        self.cost_lst = [self.cost]
+
+        self.start_time = time.time()
+        self.iter = 1
+        self.verbose = True
+
+    # ---- validation: irs_lqr/irs_lqr.py:73-103 ----------------------------
+    def check_valid_system(self, system):
+        if system.dim_x == 0:
+            raise RuntimeError("System has zero states. Did you forget to set dim_x?")
+        elif system.dim_u == 0:
+            raise RuntimeError("System has zero inputs. Did you forget to set dim_u?")
+        try:
+            system.dynamics(np.zeros(system.dim_x), np.zeros(system.dim_u))
+        except Exception:
+            raise RuntimeError("Could not evaluate dynamics. Have you implemented it?")
+
+    def check_valid_params(self, params, system):
+        if params.Q.shape != (system.dim_x, system.dim_x):
+            raise RuntimeError("Q matrix must be diagonal with dim_x x dim_x.")
+        if params.Qd.shape != (system.dim_x, system.dim_x):
+            raise RuntimeError("Qd matrix must be diagonal with dim_x x dim_x.")
+        if params.R.shape != (system.dim_u, system.dim_u):
+            raise RuntimeError("R matrix must be diagonal with dim_u x dim_u.")
+
+    # ---- irs_lqr/irs_lqr.py:105-137 ----------------------------------------
+    def rollout(self, x0, u_trj):
+        x_trj, _ = self._dm.rollout_cost(dev.to_dev(np.asarray(x0, float)), dev.to_dev(np.asarray(u_trj, float)),
+                                         self._Q, self._R, self._xd)
+        return x_trj.cpu().numpy()
+
+    def evaluate_cost(self, x_trj, u_trj):
+        cost = dev.evaluate_cost(dev.to_dev(np.asarray(x_trj, float)), dev.to_dev(np.asarray(u_trj, float)),
+                                 self._Q, self._R, self._xd)
+        return float(cost.item())
+
+    # ---- linearisation -----------------------------------------------------
+    def get_TV_matrices(self, x_trj, u_trj):
+        At, Bt, ct = self._get_TV_matrices_dev(dev.to_dev(np.asarray(x_trj, float)),
+                                               dev.to_dev(np.asarray(u_trj, float)))
+        self._check_smooth_info()
+        return At.cpu().numpy(), Bt.cpu().numpy(), ct.cpu().numpy()
+
+    def _get_TV_matrices_dev(self, x_trj, u_trj):
+        raise NotImplementedError("This class is virtual.")
+
+    # ---- irs_lqr/irs_lqr.py:148-186 ----------------------------------------
+    def local_descent(self, x_trj, u_trj):
+        x_new, u_new, _ = self._local_descent_dev(dev.to_dev(np.asarray(x_trj, float)),
+                                                  dev.to_dev(np.asarray(u_trj, float)))
+        return x_new.cpu().numpy(), u_new.cpu().numpy()
+
+    def _local_descent_dev(self, x_trj, u_trj):
+        At, Bt, ct = self._get_TV_matrices_dev(x_trj, u_trj)
+        # T MPC re-solves of the tail QP == one Riccati pass + closed-loop rollout
+        # while the box bounds are inactive (checked below).
+        K, k, info = dev.tvlqr_riccati(At, Bt, ct, self._Q, self._Qd, self._R, self._xd, alpha_R=0.5)
+        x_new, u_new, cost = self._dm.closed_loop_rollout(K, k, x_trj[0].contiguous(), self._Q, self._R, self._xd)
+        self._last = dict(At=At, Bt=Bt, ct=ct, K=K, k=k, info=info)
+        return x_new, u_new, cost
+
+    def _check_smooth_info(self):
+        info = getattr(self, "_smooth_info", None)
+        if info is not None and bool((info != 0).any().item()):
+            t = int(torch.nonzero(info)[0].item())
+            raise ValueError("randomized-smoothing least squares is rank deficient at t=%d "
+                             "(Gram matrix not positive definite; need more samples or a non-zero std)" % t)
+
+    def _check_bounds_inactive(self, x_new, u_new):
+        tol = 1e-9
+        if self.xbound is not None:
+            lo, hi = np.asarray(self.xbound[0], float), np.asarray(self.xbound[1], float)
+            if (x_new < lo - tol).any() or (x_new > hi + tol).any():
+                raise NotImplementedError(
+                    "state bounds became active: the box-constrained TV-LQR of tv_lqr.py:112-123 "
+                    "is not implemented on device yet")
+        if self.ubound is not None:
+            lo, hi = np.asarray(self.ubound[0], float), np.asarray(self.ubound[1], float)
+            if (u_new < lo - tol).any() or (u_new > hi + tol).any():
+                raise NotImplementedError(
+                    "input bounds became active: the box-constrained TV-LQR of tv_lqr.py:112-123 "
+                    "is not implemented on device yet")
+
+    # ---- irs_lqr/irs_lqr.py:188-218 ----------------------------------------
+    def iterate(self, max_iterations):
+        x_dev = dev.to_dev(np.asarray(self.x_trj, float))
+        u_dev = dev.to_dev(np.asarray(self.u_trj, float))
+        while True:
+            x_new_d, u_new_d, cost_d = self._local_descent_dev(x_dev, u_dev)
+            x_trj_new = x_new_d.cpu().numpy()
+            u_trj_new = u_new_d.cpu().numpy()
+            cost_new = float(cost_d.item())
+            if int(self._last["info"].item()) != 0:
+                raise ValueError("TV_LQR failed. Optimization problem is not solved.")
+            self._check_smooth_info()
+            self._check_bounds_inactive(x_trj_new, u_trj_new)
+
+            if self.verbose:
+                print("Iteration: {:02d} ".format(self.iter) + " || " +
+                      "Current Cost: {0:05f} ".format(cost_new) + " || " +
+                      "Elapsed time: {0:05f} ".format(time.time() - self.start_time))
+
+            self.x_trj_lst.append(x_trj_new)
+            self.u_trj_lst.append(u_trj_new)
+            self.cost_lst.append(cost_new)
+
+            if self.iter > max_iterations:
+                break
+
+            self.cost = cost_new
+            self.x_trj = x_trj_new
+            self.u_trj = u_trj_new
+            x_dev, u_dev = x_new_d, u_new_d
+            self.iter += 1
+
+        return self.x_trj, self.u_trj, self.cost
+
+
+class _IrsLqrSampled(IrsLqr):
+    MODE = None
+
+    def __init__(self, system, params, sampling):
+        super().__init__(system, params)
+        self.sampling = sampling
+
+    def _draw_host(self, x_trj, u_trj):
+        """The reference's per-timestep closure calls (irs_lqr_zero_order.py:50),
+        in the same order, stacked to (T,N,n) / (T,N,m)."""
+        xh = x_trj.cpu().numpy()
+        uh = u_trj.cpu().numpy()
+        dxs, dus = [], []
+        for t in range(self.T):
+            dx, du = self.sampling(xh[t], uh[t], self.iter)
+            dxs.append(np.asarray(dx, np.float32))
+            dus.append(np.asarray(du, np.float32))
+        return np.stack(dxs), np.stack(dus)
+
+    def _get_TV_matrices_dev(self, x_trj, u_trj):
+        rank, world = dist_util.rank_world()
+        if isinstance(self.sampling, GaussianSmoothing) and getattr(self.sampling, "on_device", True):
+            N = self.sampling.num_samples
+            lo, hi = dist_util.shard_range(N, rank, world)
+            sx, su = self.sampling.stds(self.iter)
+            sums = self._dm.smooth_accumulate_rng(self.MODE, x_trj, u_trj, hi - lo, sx, su,
+                                                  self.sampling.seed, self.iter, sample_offset=lo)
+        else:
+            dx, du = self._draw_host(x_trj, u_trj)
+            N = du.shape[1]
+            lo, hi = dist_util.shard_range(N, rank, world)
+            dxd = dev.to_dev(np.ascontiguousarray(dx[:, lo:hi]), dev.F32)
+            dud = dev.to_dev(np.ascontiguousarray(du[:, lo:hi]), dev.F32)
+            sums = self._dm.smooth_accumulate(self.MODE, x_trj, u_trj, dxd, dud)
+        dist_util.all_reduce_sums(sums)
+        At, Bt, ct, info = self._dm.smooth_finalize(self.MODE, N, x_trj, u_trj, sums)
+        self._smooth_info = info
+        return At, Bt, ct
+
+
+class IrsLqrZeroOrder(_IrsLqrSampled):
+    """irs_lqr/irs_lqr_zero_order.py:5-63."""
+    MODE = SMOOTH_ZERO_ORDER_AB
+
+    def compute_least_squares(self, dxdu, deltaf):
+        """irs_lqr_zero_order.py:27-36, for callers that use it stand-alone: the same
+        normal-equation solve the device performs, fed through the device finalize."""
+        raise NotImplementedError("compute_least_squares is fused into the device sample pass; "
+                                  "use get_TV_matrices")
+
+
+class IrsLqrFirstOrder(_IrsLqrSampled):
+    """irs_lqr/irs_lqr_first_order.py:6-54."""
+    MODE = SMOOTH_FIRST_ORDER
+
+
+class IrsLqrExact(IrsLqr):
+    """irs_lqr/irs_lqr_exact.py:6-31."""
+
+    def _get_TV_matrices_dev(self, x_trj, u_trj):
+        return self._dm.exact_linearize(x_trj, u_trj)

@@ -478,3 +478,42 @@ def device_gaussian_samples(T, N, n, m, std_x, std_u, seed, it,
                 z[t, :, 4 * j + 2 * pair + 1] = rad * np.sin(ang)
     z = z[:, :, :d] * std
     return z[:, :, :n].astype(dtype), z[:, :, n:].astype(dtype)
+
+
+# --------------------------------------------------------------------------
+# Sufficient-statistics ("Gram") form of the zero-order fit.  Algebraically the
+# same estimator as compute_least_squares (normal equations of the lstsq at
+# irs_lqr_zero_order.py:33); this is the form that shards over devices: the
+# sums of disjoint sample subsets ADD.  Used by tests to check the sharding /
+# all-reduce logic and the device `sums` buffers.
+# --------------------------------------------------------------------------
+def zero_order_sums(system, x_trj, u_trj, dx, du):
+    """(T,P) with P = d(d+1)/2 + d*n: upper-triangular Gram of z=[dx|du] followed
+    by z (f(x+dx,u+du)-f(x,u))', row-major -- the layout of irs_hip.h `sums`."""
+    T, n, m = u_trj.shape[0], system.dim_x, system.dim_u
+    d = n + m
+    iu = np.triu_indices(d)
+    out = np.zeros((T, d * (d + 1) // 2 + d * n))
+    for t in range(T):
+        z = np.hstack((dx[t], du[t]))
+        df = system.dynamics_batch(x_trj[t] + dx[t], u_trj[t] + du[t]) - system.dynamics(x_trj[t], u_trj[t])
+        out[t, :len(iu[0])] = (z.T @ z)[iu]
+        out[t, len(iu[0]):] = (z.T @ df).ravel()
+    return out
+
+
+def zero_order_from_sums(system, x_trj, u_trj, sums):
+    T, n, m = u_trj.shape[0], system.dim_x, system.dim_u
+    d = n + m
+    iu = np.triu_indices(d)
+    ng = len(iu[0])
+    At, Bt, ct = np.zeros((T, n, n)), np.zeros((T, n, m)), np.zeros((T, n))
+    for t in range(T):
+        G = np.zeros((d, d))
+        G[iu] = sums[t, :ng]
+        G = G + np.triu(G, 1).T
+        H = sums[t, ng:].reshape(d, n)
+        AB = np.linalg.solve(G, H).T
+        At[t], Bt[t] = AB[:, :n], AB[:, n:]
+        ct[t] = system.dynamics(x_trj[t], u_trj[t]) - At[t].dot(x_trj[t]) - Bt[t].dot(u_trj[t])
+    return At, Bt, ct

@@ -1,0 +1,86 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and
+exports every symbol include/irs_hip.h declares; argument validation returns error
+codes without touching a GPU.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    from irs_mpc_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        g.build()
+    return _lib.load()
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "irs_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(irs_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_header_symbol_is_exported_and_bound(lib):
+    from irs_mpc_amd import _lib
+    syms = header_symbols()
+    assert len(syms) >= 17
+    for s in syms:
+        assert hasattr(lib, s), "libirs_hip.so does not export %s" % s
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes table and header disagree"
+
+
+def test_model_registry(lib):
+    n, m, k = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert lib.irs_model_info(0, n, m, k) == 0 and (n.value, m.value, k.value) == (2, 1, 1)
+    assert lib.irs_model_info(1, n, m, k) == 0 and (n.value, m.value, k.value) == (12, 4, 9)
+    assert lib.irs_model_info(99, n, m, k) == -3
+    assert b"unknown model" in lib.irs_last_error()
+    # P = d(d+1)/2 + d n  |  n d  |  m(m+1)/2 + m n
+    assert [lib.irs_sums_len(0, mode) for mode in range(3)] == [12, 6, 3]
+    assert [lib.irs_sums_len(1, mode) for mode in range(3)] == [136 + 192, 192, 10 + 48]
+    assert lib.irs_sums_len(0, 7) == -1
+    assert lib.irs_smooth_workspace_bytes(0, 0, 30, 10000) > 0
+
+
+def test_argument_validation_without_gpu(lib):
+    from irs_mpc_amd._lib import dbl_array
+    p = dbl_array([0.05])
+    assert lib.irs_tvlqr_riccati(0, 1, 5, None, None, None, None, None, None, 0.5, None, None, None, None, None) == -1
+    assert lib.irs_tvlqr_riccati(40, 1, 5, None, None, None, None, None, None, 0.5, None, None, None, None, None) == -1
+    assert lib.irs_smooth_accumulate(0, p, 1, 0, 30, 0, None, None, None, None, None, None, 0, None) == -1
+    assert lib.irs_dynamics_batch(0, p, 1, None, None, 0, None, None) == -1
+    assert lib.irs_smooth_finalize(0, p, 1, 9, 30, 10, None, None, None, None, None, None, None, None) == -1
+    assert lib.irs_last_error() != b""
+
+
+def test_product_does_not_import_oracle():
+    """The shipped package must never route through the oracle."""
+    pkg = os.path.join(ROOT, "irs_mpc_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from irs_mpc_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import numpy as np
+    from irs_mpc_amd import PendulumDynamics
+    with pytest.raises(RuntimeError, match="needs an AMD GPU"):
+        PendulumDynamics(0.05).dynamics_batch(np.zeros((1, 2)), np.zeros((1, 1)))

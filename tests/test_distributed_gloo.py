@@ -1,0 +1,66 @@
+"""N>1 path on CPU: two gloo ranks shard the samples of every timestep, reduce their
+shard to sufficient statistics, all-reduce once, and solve redundantly -- the
+product's irs_mpc_amd.distributed helpers, with the oracle standing in for the
+device sample pass.  Result must equal the unsharded estimator."""
+import os
+import sys
+
+import numpy as np
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, T, N, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    from oracle import irs_oracle as orc
+    from irs_mpc_amd.distributed import all_reduce_sums, rank_world, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert rank_world() == (rank, world)
+    s = orc.PendulumOracle(0.05)
+    u = np.tile(np.array([0.1]), (T, 1))
+    x = orc.rollout(s, np.zeros(2), u)
+    rng = np.random.default_rng(0)              # every rank draws the same full set
+    dx, du = rng.normal(size=(T, N, 2)), rng.normal(size=(T, N, 1))
+    lo, hi = shard_range(N, rank, world)
+    sums = torch.from_numpy(orc.zero_order_sums(s, x, u, dx[:, lo:hi], du[:, lo:hi]))
+    all_reduce_sums(sums)
+    At, Bt, ct = orc.zero_order_from_sums(s, x, u, sums.numpy())
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), At=At, Bt=Bt, ct=ct, lo=lo, hi=hi)
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_smoothing_equals_unsharded(tmp_path):
+    from oracle import irs_oracle as orc
+    T, N, world = 6, 1001, 2
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(world, port, T, N, str(tmp_path)), nprocs=world, join=True)
+    r0 = np.load(tmp_path / "r0.npz")
+    r1 = np.load(tmp_path / "r1.npz")
+    assert (int(r0["lo"]), int(r0["hi"]), int(r1["lo"]), int(r1["hi"])) == (0, 501, 501, 1001)
+    for k in ("At", "Bt", "ct"):
+        assert np.array_equal(r0[k], r1[k])          # every rank holds the same answer
+    s = orc.PendulumOracle(0.05)
+    u = np.tile(np.array([0.1]), (T, 1))
+    x = orc.rollout(s, np.zeros(2), u)
+    rng = np.random.default_rng(0)
+    dx, du = rng.normal(size=(T, N, 2)), rng.normal(size=(T, N, 1))
+    At, Bt, ct = orc.zero_order_TV(s, x, u, dx, du)  # lstsq on all samples
+    np.testing.assert_allclose(r0["At"], At, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(r0["Bt"], Bt, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(r0["ct"], ct, rtol=1e-9, atol=1e-11)
+
+
+def test_shard_range_partitions():
+    from irs_mpc_amd.distributed import shard_range
+    for N in (1, 7, 8, 1000, 100003):
+        for W in (1, 2, 3, 8):
+            edges = [shard_range(N, r, W) for r in range(W)]
+            assert edges[0][0] == 0 and edges[-1][1] == N
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(W - 1))
+            sizes = [hi - lo for lo, hi in edges]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,418 @@
+"""GPU parity tests: the HIP path (through the C ABI) vs the reference-run golden
+fixtures and vs the NumPy oracle on identical inputs.
+
+Tolerances.  Everything computed in f64 on the device (dynamics/Jacobian plugin
+calls, rollouts, Riccati, costs) is held to ~1e-10.  The sample pass evaluates the
+dynamics in f32 on f32 samples: A_t, B_t, c_t are held to rtol 1e-4 / atol 2e-5 of
+the f64 reference ("fp32 tolerance" of BASELINE.json), the resulting trajectories
+and costs to rtol 1e-4.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import irs_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL_AB = dict(rtol=1e-4, atol=2e-5)
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import irs_mpc_amd
+    from irs_mpc_amd import _lib
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    _lib.load()     # fails loudly if the HIP library is missing
+    return irs_mpc_amd
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def pend_params(amd, T):
+    p = amd.IrsLqrParameters()
+    p.Q, p.Qd, p.R = np.diag([1., 1.]), np.diag([20., 20.]), np.diag([1.])
+    p.x0 = np.array([0., 0.])
+    p.xd_trj = np.tile(np.array([np.pi, 0.]), (T + 1, 1))
+    p.u_trj_initial = np.tile(np.array([0.1]), (T, 1))
+    p.xbound = [-np.array([1e4, 1e4]), np.array([1e4, 1e4])]
+    p.ubound = np.array([-np.array([1e4]), np.array([1e4])])
+    return p
+
+
+def quad_params(amd, T):
+    p = amd.IrsLqrParameters()
+    p.Q = np.diag([10., 10, 10, 10, 10, 10, 0, 0, 0, 0, 0, 0])
+    p.Qd = 10.0 * np.diag([10., 10, 10, 10, 10, 10, 1, 1, 1, 1, 1, 1])
+    p.R = np.eye(4)
+    p.x0 = np.zeros(12)
+    p.xd_trj = np.zeros((T + 1, 12))
+    for i in range(T + 1):
+        p.xd_trj[i, :3] = [1.5 * np.cos(0.05 * i), 1.5 * np.sin(0.05 * i), 0.02 * i]
+    p.u_trj_initial = np.tile(np.array([2.0, 2.0, 2.0, 2.0]), (T, 1))
+    return p
+
+
+def systems(amd, name, h=0.05):
+    if name == "pendulum":
+        return amd.PendulumDynamics(h), orc.PendulumOracle(h)
+    return amd.QuadrotorDynamics(h), orc.QuadrotorOracle(h)
+
+
+class Replay:
+    """sampling closure that replays recorded draws (one (N,n),(N,m) pair per call)."""
+
+    def __init__(self, dx, du):
+        self.dx, self.du, self.i = dx, du, 0
+
+    def __call__(self, x, u, it):
+        i = self.i
+        self.i += 1
+        return self.dx[i], self.du[i]
+
+
+# ---------------------------------------------------------------- plugin surface
+@pytest.mark.parametrize("name", ["pendulum", "quadrotor"])
+def test_dynamics_batch_vs_reference_fixture(amd, golden_dir, name):
+    f = load(golden_dir, name + "_dynamics")
+    sys_d, _ = systems(amd, name, float(f["h"]))
+    Xn = sys_d.dynamics_batch(f["X"], f["U"])
+    np.testing.assert_allclose(Xn, f["Xn"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(sys_d.dynamics(f["X"][3], f["U"][3]), f["Xn"][3], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["pendulum", "quadrotor"])
+def test_jacobian_batch_vs_oracle(amd, name):
+    sys_d, sys_o = systems(amd, name)
+    rng = np.random.default_rng(3)
+    X = rng.normal(size=(40, sys_o.dim_x)) * 0.5
+    U = 2.0 + rng.normal(size=(40, sys_o.dim_u)) * 0.5
+    J = sys_d.jacobian_xu_batch(X, U)
+    np.testing.assert_allclose(J, sys_o.jacobian_xu_batch(X, U), rtol=0, atol=1e-11)
+    np.testing.assert_allclose(sys_d.jacobian_xu(X[0], U[0]), sys_o.jacobian_xu(X[0], U[0]), rtol=0, atol=1e-11)
+
+
+def test_rollout_and_cost_vs_reference_fixture(amd, golden_dir):
+    f = load(golden_dir, "pendulum_T200_init")
+    sol = amd.IrsLqrExact(amd.PendulumDynamics(0.05), pend_params(amd, 200))
+    np.testing.assert_allclose(sol.x_trj, f["x_trj"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(sol.cost, float(f["cost0"]), rtol=1e-13)
+    f = load(golden_dir, "quadrotor_T200_init")
+    sol = amd.IrsLqrExact(amd.QuadrotorDynamics(0.05), quad_params(amd, 200))
+    np.testing.assert_allclose(sol.x_trj, f["x_trj"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(sol.cost, float(f["cost0"]), rtol=1e-12)
+    # evaluate_cost of a pair that is NOT dynamically consistent
+    rng = np.random.default_rng(0)
+    x, u = rng.normal(size=(201, 12)), rng.normal(size=(200, 4))
+    p = quad_params(amd, 200)
+    np.testing.assert_allclose(sol.evaluate_cost(x, u), orc.evaluate_cost(x, u, p.xd_trj, p.Q, p.R), rtol=1e-12)
+
+
+# ---------------------------------------------------------------- smoothing vs REFERENCE outputs
+@pytest.mark.parametrize("fix,name,T", [("pendulum_zero_T30_N100", "pendulum", 30),
+                                        ("quadrotor_zero_T6_N64", "quadrotor", 6)])
+def test_zero_order_vs_reference_fixture(amd, golden_dir, fix, name, T):
+    f = load(golden_dir, fix)
+    sys_d, _ = systems(amd, name, float(f["h"]))
+    params = (pend_params if name == "pendulum" else quad_params)(amd, T)
+    sol = amd.IrsLqrZeroOrder(sys_d, params, Replay(f["dx"], f["du"]))
+    np.testing.assert_allclose(sol.x_trj, f["x_trj"], rtol=0, atol=1e-10)
+    At, Bt, ct = sol.get_TV_matrices(sol.x_trj, sol.u_trj)
+    np.testing.assert_allclose(At, f["At"], **TOL_AB)
+    np.testing.assert_allclose(Bt, f["Bt"], **TOL_AB)
+    np.testing.assert_allclose(ct, f["ct"], **TOL_AB)
+
+
+def test_zero_order_identical_seed_as_reference(amd, golden_dir):
+    """np.random.seed + the script's closure: the device path consumes the very
+    samples the reference run consumed (fixture recorded with seed 0)."""
+    f = load(golden_dir, "pendulum_zero_T30_N100")
+    N = 100
+
+    def sampling(xbar, ubar, it):      # pendulum_zero_order.py:38-43
+        dx = np.random.normal(0.0, np.array([1.0, 1.0]) / it ** 0.5, size=(N, 2))
+        du = np.random.normal(0.0, np.array([1.0]) / it ** 0.5, size=(N, 1))
+        return dx, du
+
+    np.random.seed(int(f["seed"]))
+    sol = amd.IrsLqrZeroOrder(amd.PendulumDynamics(0.05), pend_params(amd, 30), sampling)
+    At, Bt, ct = sol.get_TV_matrices(sol.x_trj, sol.u_trj)
+    np.testing.assert_allclose(At, f["At"], **TOL_AB)
+    np.testing.assert_allclose(Bt, f["Bt"], **TOL_AB)
+    np.testing.assert_allclose(ct, f["ct"], **TOL_AB)
+
+
+def test_first_order_vs_reference_fixture(amd, golden_dir):
+    f = load(golden_dir, "pendulum_first_T30_N100")
+    sol = amd.IrsLqrFirstOrder(amd.PendulumDynamics(0.05), pend_params(amd, 30), Replay(f["dx"], f["du"]))
+    At, Bt, ct = sol.get_TV_matrices(sol.x_trj, sol.u_trj)
+    np.testing.assert_allclose(At, f["At"], **TOL_AB)
+    np.testing.assert_allclose(Bt, f["Bt"], **TOL_AB)
+    np.testing.assert_allclose(ct, f["ct"], **TOL_AB)
+
+
+# ---------------------------------------------------------------- smoothing vs oracle, more shapes
+@pytest.mark.parametrize("name,T,N,std", [("pendulum", 30, 10000, 1.0), ("pendulum", 30, 100000, 0.3),
+                                          ("pendulum", 7, 1, 1.0), ("pendulum", 3, 257, 1.0),
+                                          ("quadrotor", 50, 300, 0.1), ("quadrotor", 4, 2000, 0.1)])
+def test_zero_order_vs_oracle(amd, name, T, N, std):
+    sys_d, sys_o = systems(amd, name)
+    n, m = sys_o.dim_x, sys_o.dim_u
+    params = (pend_params if name == "pendulum" else quad_params)(amd, T)
+    rng = np.random.default_rng(T * 1000 + N)
+    dx = (rng.normal(size=(T, N, n)) * std).astype(np.float32)
+    du = (rng.normal(size=(T, N, m)) * std).astype(np.float32)
+    sol = amd.IrsLqrZeroOrder(sys_d, params, Replay(dx, du))
+    if N < n + m:
+        with pytest.raises(ValueError, match="rank deficient"):
+            sol.get_TV_matrices(sol.x_trj, sol.u_trj)
+        return
+    At, Bt, ct = sol.get_TV_matrices(sol.x_trj, sol.u_trj)
+    Ao, Bo, co = orc.zero_order_TV(sys_o, sol.x_trj, sol.u_trj, dx.astype(np.float64), du.astype(np.float64))
+    np.testing.assert_allclose(At, Ao, **TOL_AB)
+    np.testing.assert_allclose(Bt, Bo, **TOL_AB)
+    np.testing.assert_allclose(ct, co, **TOL_AB)
+
+
+@pytest.mark.parametrize("name,T,N,std", [("pendulum", 30, 5000, 1.0), ("pendulum", 5, 1, 0.5),
+                                          ("quadrotor", 5, 333, 0.1), ("quadrotor", 50, 64, 0.1)])
+def test_first_order_vs_oracle(amd, name, T, N, std):
+    sys_d, sys_o = systems(amd, name)
+    n, m = sys_o.dim_x, sys_o.dim_u
+    params = (pend_params if name == "pendulum" else quad_params)(amd, T)
+    rng = np.random.default_rng(T * 1000 + N + 1)
+    dx = (rng.normal(size=(T, N, n)) * std).astype(np.float32)
+    du = (rng.normal(size=(T, N, m)) * std).astype(np.float32)
+    sol = amd.IrsLqrFirstOrder(sys_d, params, Replay(dx, du))
+    At, Bt, ct = sol.get_TV_matrices(sol.x_trj, sol.u_trj)
+    Ao, Bo, co = orc.first_order_TV(sys_o, sol.x_trj, sol.u_trj, dx.astype(np.float64), du.astype(np.float64))
+    np.testing.assert_allclose(At, Ao, **TOL_AB)
+    np.testing.assert_allclose(Bt, Bo, **TOL_AB)
+    np.testing.assert_allclose(ct, co, **TOL_AB)
+
+
+def test_first_order_zero_std_equals_exact(amd):
+    """Size-independent property at BASELINE config 2's full size (quadrotor T=50,
+    N=10000): with zero perturbations the mean Jacobian is the exact linearisation."""
+    T, N = 50, 10000
+    sys_d, _ = systems(amd, "quadrotor")
+    dx = np.zeros((T, N, 12), np.float32)
+    du = np.zeros((T, N, 4), np.float32)
+    sol = amd.IrsLqrFirstOrder(sys_d, quad_params(amd, T), Replay(dx, du))
+    At, Bt, ct = sol.get_TV_matrices(sol.x_trj, sol.u_trj)
+    ex = amd.IrsLqrExact(sys_d, quad_params(amd, T))
+    Ae, Be, ce = ex.get_TV_matrices(ex.x_trj, ex.u_trj)
+    np.testing.assert_allclose(At, Ae, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(Bt, Be, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(ct, ce, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("name,T,N", [("pendulum", 10, 4000), ("quadrotor", 5, 1000)])
+def test_zero_order_B_vs_oracle(amd, name, T, N):
+    """quasistatic_dynamics.py:242-266 estimator: u-only noise, A exact."""
+    from irs_mpc_amd import device as dev
+    from irs_mpc_amd._lib import SMOOTH_ZERO_ORDER_B
+    sys_d, sys_o = systems(amd, name)
+    n, m = sys_o.dim_x, sys_o.dim_u
+    params = (pend_params if name == "pendulum" else quad_params)(amd, T)
+    x_trj = orc.rollout(sys_o, params.x0, params.u_trj_initial)
+    rng = np.random.default_rng(9)
+    du = (rng.normal(size=(T, N, m)) * 0.2).astype(np.float32)
+    dm = sys_d.dm()
+    xd, ud = dev.to_dev(x_trj), dev.to_dev(params.u_trj_initial)
+    sums = dm.smooth_accumulate(SMOOTH_ZERO_ORDER_B, xd, ud, None, dev.to_dev(du, dev.F32))
+    At, Bt, ct, info = dm.smooth_finalize(SMOOTH_ZERO_ORDER_B, N, xd, ud, sums)
+    assert int(info.abs().sum().item()) == 0
+    for t in range(T):
+        x, u = x_trj[t], params.u_trj_initial[t]
+        fn = sys_o.dynamics_batch(np.tile(x, (N, 1)), u + du[t].astype(np.float64))
+        B = orc.zero_order_B_fit(du[t].astype(np.float64), fn - sys_o.dynamics(x, u))
+        A = sys_o.jacobian_xu(x, u)[:, :n]
+        np.testing.assert_allclose(Bt[t].cpu().numpy(), B, **TOL_AB)
+        np.testing.assert_allclose(At[t].cpu().numpy(), A, rtol=0, atol=1e-11)
+        np.testing.assert_allclose(ct[t].cpu().numpy(), sys_o.dynamics(x, u) - A.dot(x) - B.dot(u), **TOL_AB)
+
+
+def test_shard_sum_invariance_full_size(amd):
+    """Multi-GPU contract at BASELINE config 3's per-GPU size: the sums of 8 logical
+    shards add up to the unsharded sums (what the all-reduce relies on)."""
+    from irs_mpc_amd import device as dev
+    from irs_mpc_amd._lib import SMOOTH_ZERO_ORDER_AB
+    from irs_mpc_amd.distributed import shard_range
+    T, N = 50, 100000
+    sys_d, sys_o = systems(amd, "pendulum")
+    params = pend_params(amd, T)
+    x_trj = dev.to_dev(orc.rollout(sys_o, params.x0, params.u_trj_initial))
+    u_trj = dev.to_dev(params.u_trj_initial)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    dx = torch.randn((T, N, 2), generator=g, device="cuda", dtype=torch.float32)
+    du = torch.randn((T, N, 1), generator=g, device="cuda", dtype=torch.float32)
+    dm = sys_d.dm()
+    full = dm.smooth_accumulate(SMOOTH_ZERO_ORDER_AB, x_trj, u_trj, dx, du).clone()
+    acc = torch.zeros_like(full)
+    for r in range(8):
+        lo, hi = shard_range(N, r, 8)
+        acc += dm.smooth_accumulate(SMOOTH_ZERO_ORDER_AB, x_trj, u_trj, dx[:, lo:hi].contiguous(),
+                                    du[:, lo:hi].contiguous())
+    np.testing.assert_allclose(acc.cpu().numpy(), full.cpu().numpy(), rtol=2e-6, atol=1e-3)
+    A1, B1, c1, _ = dm.smooth_finalize(SMOOTH_ZERO_ORDER_AB, N, x_trj, u_trj, full)
+    A2, B2, c2, _ = dm.smooth_finalize(SMOOTH_ZERO_ORDER_AB, N, x_trj, u_trj, acc)
+    np.testing.assert_allclose(A1.cpu().numpy(), A2.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    # run-to-run determinism (fixed-order reductions, no atomics)
+    again = dm.smooth_accumulate(SMOOTH_ZERO_ORDER_AB, x_trj, u_trj, dx, du)
+    assert torch.equal(again, full)
+
+
+# ---------------------------------------------------------------- device RNG (mode G)
+def test_device_rng_matches_specification(amd):
+    dm = amd.QuadrotorDynamics(0.05).dm()
+    std_x, std_u = 0.1 * np.arange(1, 13), 0.2 * np.arange(1, 5)
+    dx, du = dm.rng_samples(3, 1000, std_x, std_u, seed=0x123456789ABC, it=4, sample_offset=77)
+    ox, ou = orc.device_gaussian_samples(3, 1000, 12, 4, std_x, std_u, 0x123456789ABC, 4, sample_offset=77)
+    np.testing.assert_allclose(dx.cpu().numpy(), ox, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(du.cpu().numpy(), ou, rtol=2e-5, atol=2e-6)
+    # the split over devices does not change the stream
+    dx2, _ = dm.rng_samples(3, 400, std_x, std_u, seed=0x123456789ABC, it=4, sample_offset=77 + 600)
+    assert torch.equal(dx2, dx[:, 600:])
+
+
+@pytest.mark.parametrize("name,cls,N", [("pendulum", "IrsLqrZeroOrder", 10000), ("quadrotor", "IrsLqrFirstOrder", 500)])
+def test_mode_G_smoothing_vs_oracle(amd, name, cls, N):
+    sys_d, sys_o = systems(amd, name)
+    n, m = sys_o.dim_x, sys_o.dim_u
+    T = 12
+    params = (pend_params if name == "pendulum" else quad_params)(amd, T)
+    sm = amd.GaussianSmoothing(0.3 * np.ones(n), 0.2 * np.ones(m), N, seed=42)
+    sol = getattr(amd, cls)(sys_d, params, sm)
+    sol.iter = 3
+    At, Bt, ct = sol.get_TV_matrices(sol.x_trj, sol.u_trj)
+    sx, su = sm.stds(3)
+    dx, du = orc.device_gaussian_samples(T, N, n, m, sx, su, 42, 3, dtype=np.float32)
+    fn = orc.zero_order_TV if cls == "IrsLqrZeroOrder" else orc.first_order_TV
+    Ao, Bo, co = fn(sys_o, sol.x_trj, sol.u_trj, dx.astype(np.float64), du.astype(np.float64))
+    np.testing.assert_allclose(At, Ao, rtol=2e-4, atol=5e-5)
+    np.testing.assert_allclose(Bt, Bo, rtol=2e-4, atol=5e-5)
+    np.testing.assert_allclose(ct, co, rtol=2e-4, atol=5e-5)
+
+
+# ---------------------------------------------------------------- TV-LQR
+@pytest.mark.parametrize("name,T", [("pendulum", 30), ("quadrotor", 50)])
+def test_riccati_gains_and_descent_vs_oracle(amd, name, T):
+    sys_d, sys_o = systems(amd, name)
+    params = (pend_params if name == "pendulum" else quad_params)(amd, T)
+    sol = amd.IrsLqrExact(sys_d, params)
+    x_new, u_new = sol.local_descent(sol.x_trj, sol.u_trj)
+    At, Bt, ct = orc.exact_TV(sys_o, sol.x_trj, sol.u_trj)
+    np.testing.assert_allclose(sol._last["At"].cpu().numpy(), At, rtol=0, atol=1e-11)
+    xo, uo, K, k = orc.local_descent(sys_o, At, Bt, ct, params.Q, params.Qd, params.R, params.x0, params.xd_trj)
+    np.testing.assert_allclose(sol._last["K"].cpu().numpy(), K, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(sol._last["k"].cpu().numpy(), k, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(u_new, uo, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(x_new, xo, rtol=1e-8, atol=1e-9)
+
+
+def test_solve_tvlqr_matches_qp(amd):
+    """tv_lqr.solve_tvlqr drop-in vs the literal QP restatement (KKT solve)."""
+    sys_o = orc.QuadrotorOracle(0.05)
+    p = quad_params(amd, 8)
+    x = orc.rollout(sys_o, p.x0, p.u_trj_initial)
+    At, Bt, ct = orc.exact_TV(sys_o, x, p.u_trj_initial)
+    xs, us = amd.solve_tvlqr(At, Bt, ct, p.Q, p.Qd, p.R, p.x0, p.xd_trj, amd.get_solver("osqp"))
+    xq, uq = orc.solve_tvlqr_qp(At, Bt, ct, p.Q, p.Qd, p.R, p.x0, p.xd_trj)
+    np.testing.assert_allclose(us, uq, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(xs, xq, rtol=1e-6, atol=1e-7)
+    with pytest.raises(NotImplementedError):
+        amd.solve_tvlqr(At, Bt, ct, p.Q, p.Qd, p.R, p.x0, p.xd_trj, None,
+                        u_bound_abs=np.stack([np.full((8, 4), -0.1), np.full((8, 4), 0.1)]))
+    with pytest.raises(ValueError):
+        amd.get_solver("nope")
+
+
+# ---------------------------------------------------------------- end to end vs the reference's result files
+def test_pendulum_exact_csv_end_to_end(amd, golden_dir):
+    gold = np.loadtxt(os.path.join(golden_dir, "pendulum_exact.csv"))
+    sol = amd.IrsLqrExact(amd.PendulumDynamics(0.05), pend_params(amd, 200))
+    sol.verbose = False
+    sol.iterate(len(gold) - 2)
+    np.testing.assert_allclose(sol.cost_lst, gold, rtol=2e-9)
+    assert len(sol.x_trj_lst) == len(gold) and sol.iter == len(gold) - 1
+
+
+def test_quadrotor_exact_csv_end_to_end(amd, golden_dir):
+    gold = np.loadtxt(os.path.join(golden_dir, "quadrotor_exact.csv"))[:5]
+    sol = amd.IrsLqrExact(amd.QuadrotorDynamics(0.05), quad_params(amd, 200))
+    sol.verbose = False
+    sol.iterate(3)
+    np.testing.assert_allclose(sol.cost_lst, gold, rtol=1e-7)
+
+
+def test_zero_order_iterate_vs_oracle_same_seed(amd):
+    """Whole iterate() loop, identical seeds: cost history vs the oracle fed the
+    same NumPy RNG stream (f32-rounded samples)."""
+    T, N = 30, 1000
+    params = pend_params(amd, T)
+
+    def sampling(xbar, ubar, it):
+        dx = np.random.normal(0.0, np.array([1.0, 1.0]) / it ** 0.5, size=(N, 2)).astype(np.float32)
+        du = np.random.normal(0.0, np.array([1.0]) / it ** 0.5, size=(N, 1)).astype(np.float32)
+        return dx, du
+
+    np.random.seed(5)
+    sol = amd.IrsLqrZeroOrder(amd.PendulumDynamics(0.05), params, sampling)
+    sol.verbose = False
+    sol.iterate(4)
+
+    sys_o = orc.PendulumOracle(0.05)
+
+    def tv(x, u, it):
+        dx = np.zeros((T, N, 2))
+        du = np.zeros((T, N, 1))
+        for t in range(T):
+            a, b = sampling(x[t], u[t], it)
+            dx[t], du[t] = a, b
+        return orc.zero_order_TV(sys_o, x, u, dx, du)
+
+    np.random.seed(5)
+    *_, cost_lst, x_lst, u_lst = orc.iterate(sys_o, params.Q, params.Qd, params.R, params.x0, params.xd_trj,
+                                             params.u_trj_initial, 4, tv)
+    np.testing.assert_allclose(sol.cost_lst, cost_lst, rtol=1e-4)
+    np.testing.assert_allclose(sol.u_trj_lst[-1], u_lst[-1], rtol=1e-3, atol=1e-3)
+
+
+def test_stochastic_band_vs_reference_csv(amd, golden_dir):
+    """Mode G (device RNG), the script's configuration (T=200, N=1000): iteration
+    costs land in the run-to-run band of the reference's own two unseeded runs."""
+    gold = np.loadtxt(os.path.join(golden_dir, "pendulum_zero_order.csv"))
+    sm = amd.GaussianSmoothing([1.0, 1.0], [1.0], 1000, seed=1)
+    sol = amd.IrsLqrZeroOrder(amd.PendulumDynamics(0.05), pend_params(amd, 200), sm)
+    sol.verbose = False
+    sol.iterate(7)
+    assert sol.cost_lst[0] == pytest.approx(gold[0], rel=1e-12)
+    np.testing.assert_allclose(sol.cost_lst[1:5], gold[1:5], rtol=0.02)
+    assert abs(sol.cost_lst[8] - gold[8]) / gold[8] < 0.005
+
+
+# ---------------------------------------------------------------- error behaviour (irs_lqr.py:73-103)
+def test_error_behaviour(amd):
+    p = pend_params(amd, 5)
+    p.Q = np.eye(3)
+    with pytest.raises(RuntimeError, match="Q matrix"):
+        amd.IrsLqrExact(amd.PendulumDynamics(0.05), p)
+
+    class Empty(amd.DynamicalSystem):
+        pass
+
+    with pytest.raises(RuntimeError, match="zero states"):
+        amd.IrsLqrExact(Empty(), pend_params(amd, 5))
+
+    class NoDevice(amd.DynamicalSystem):
+        def __init__(self):
+            super().__init__()
+            self.dim_x, self.dim_u, self.h = 2, 1, 0.1
+
+    with pytest.raises(RuntimeError, match="Could not evaluate dynamics"):
+        amd.IrsLqrExact(NoDevice(), pend_params(amd, 5))
