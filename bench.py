@@ -1,15 +1,16 @@
 #!/usr/bin/env python3
 """Headline benchmark: rollouts x timesteps / s of the randomised-smoothing pass
 (get_TV_matrices: sample pass + reduction + solve -> A_t,B_t,c_t) and iLQR
-iterations / s (that + Riccati + closed-loop rollout + cost), BASELINE.json config 1:
+iterations / s (that + Riccati + closed-loop rollout + cost), BASELINE.json configs[1]:
 pendulum zero-order, T=30, N=10000 samples per timestep PER GPU, samples resident in
 HBM (f32).  One process per GPU; N>1 is launched by torch.distributed.run.
 
     python bench.py --gpus 1 --steps 200 --warmup 20
 
-A "step" = one smoothing pass over the (T x N) sample grid.  With --gpus N every rank
-holds its own N samples per timestep (weak scaling) and the (T,P) f64 statistics are
-all-reduced (RCCL) inside every step.  Prints ONE JSON line on rank 0.
+A "step" = one smoothing pass over the (T x N) sample grid = ONE kernel launch on one
+GPU.  With --gpus N every rank holds its own N samples per timestep (weak scaling) and
+the (T,P) f64 statistics are all-reduced (RCCL) inside every step, followed by the
+solve launch.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -85,22 +86,7 @@ def main():
     x0 = dev.to_dev(np.zeros(2))
     u_trj = dev.to_dev(np.tile(np.array([0.1]), (T, 1)))
     x_trj, _ = dm.rollout_cost(x0, u_trj, Q, R, xd)
-
-    def make_samples(N):
-        g = torch.Generator(device="cuda").manual_seed(1234 + rank)
-        dx = torch.randn((T, N, n), generator=g, device="cuda", dtype=torch.float32)
-        du = torch.randn((T, N, m), generator=g, device="cuda", dtype=torch.float32)
-        return dx, du
-
-    def smooth_step(dx, du, sums, n_total):
-        dm.smooth_accumulate(MODE, x_trj, u_trj, dx, du, sums=sums)
-        all_reduce_sums(sums)
-        return dm.smooth_finalize(MODE, n_total, x_trj, u_trj, sums)
-
-    def ilqr_step(dx, du, sums, n_total):
-        At, Bt, ct, info = smooth_step(dx, du, sums, n_total)
-        K, k, _ = dev.tvlqr_riccati(At, Bt, ct, Q, Qd, R, xd, alpha_R=0.5)
-        return dm.closed_loop_rollout(K, k, x0, Q, R, xd)
+    stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
         if world > 1:
@@ -124,33 +110,74 @@ def main():
             el = float(t.item())
         return el
 
-    def kernel_time_ms(dx, du, sums, reps):
-        """Average duration of the sample pass measured with HIP events on the stream
-        the kernels are launched on (torch's current stream is the one passed to the C ABI)."""
-        starts = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
-        ends = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
-        for i in range(reps):
-            starts[i].record()
-            dm.smooth_accumulate(MODE, x_trj, u_trj, dx, du, sums=sums)
-            ends[i].record()
-        torch.cuda.synchronize()
-        ts = sorted(s.elapsed_time(e) for s, e in zip(starts, ends))
-        return float(np.mean(ts)), float(ts[len(ts) // 2])
-
     def run(N, steps, warmup):
-        dx, du = make_samples(N)
-        sums = torch.empty((T, dm.sums_len(MODE)), dtype=torch.float64, device="cuda")
+        g = torch.Generator(device="cuda").manual_seed(1234 + rank)
+        dx = torch.randn((T, N, n), generator=g, device="cuda", dtype=torch.float32)
+        du = torch.randn((T, N, m), generator=g, device="cuda", dtype=torch.float32)
         n_total = N * world
-        el = timed(lambda: smooth_step(dx, du, sums, n_total), steps, warmup)
-        el_it = timed(lambda: ilqr_step(dx, du, sums, n_total), steps, warmup)
-        k_mean, k_med = kernel_time_ms(dx, du, sums, min(steps, 200))
-        return el, el_it, k_mean, k_med
+        if world == 1:
+            plan = dev.SmoothPlan(dm, MODE, x_trj, u_trj, dx=dx, du=du, fuse=True)
+            tv = plan.out
+
+            def smooth_step():
+                plan.run(stream)
+        else:
+            plan = dev.SmoothPlan(dm, MODE, x_trj, u_trj, dx=dx, du=du, fuse=False, n_total=n_total)
+            tv = {}
+
+            def smooth_step():
+                plan.run(stream)
+                all_reduce_sums(plan.sums)
+                tv["At"], tv["Bt"], tv["ct"], tv["info"] = dm.smooth_finalize(MODE, n_total, x_trj, u_trj, plan.sums)
+
+        smooth_step()
+        descent = dev.DescentPlan(dm, tv["At"], tv["Bt"], tv["ct"], Q, Qd, R, xd, x0)
+
+        def ilqr_step():
+            smooth_step()
+            if world > 1:       # finalize allocated fresh outputs
+                c = descent.call
+                c.At, c.Bt, c.ct = tv["At"].data_ptr(), tv["Bt"].data_ptr(), tv["ct"].data_ptr()
+            descent.run(stream)
+
+        el = timed(smooth_step, steps, warmup)
+        el_it = timed(ilqr_step, steps, warmup)
+        # Duration of the sample-pass kernel: HIP events recorded on the stream the kernel
+        # is launched on (torch's current stream is the one handed to the C ABI).
+        reps = min(steps, 200)
+
+        def event_pairs(body):
+            starts = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+            ends = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+            for i in range(reps):
+                starts[i].record()
+                body()
+                ends[i].record()
+            torch.cuda.synchronize()
+            return sorted(s.elapsed_time(e) for s, e in zip(starts, ends))
+
+        ts = event_pairs(lambda: plan.run(stream))
+        empty = event_pairs(lambda: None)          # what an event pair costs with nothing between
+        ovh = float(np.median(empty))
+        return el, el_it, float(np.mean(ts)), float(ts[len(ts) // 2]), ovh
 
     N = args.N
-    el, el_it, k_mean, k_med = run(N, args.steps, args.warmup)
+    el, el_it, k_raw, k_med, ovh = run(N, args.steps, args.warmup)
+    k_mean = max(k_raw - ovh, 1e-6)                # launch duration net of the event pair's own cost
     bytes_per_sample_step = 4 * (n + m)            # SURVEY 8(d): dx,du read once, f32
     alg_bytes = bytes_per_sample_step * N * T      # per launch (per GPU)
     achieved = alg_bytes / (k_mean * 1e-3) / 1e9
+
+    # HBM traffic per launch from the PMC passes of tools/profile_round.sh (separate
+    # rocprofv3 --pmc runs of this same command; FETCH_SIZE doubled as the gfx950 note in
+    # MI355X_MICROARCH.md prescribes, and it then matches the known byte count).
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path)).get("pendulum_zero_T%d_N%d" % (T, N))
+        if pmc and "FETCH_SIZE_raw_avg" in pmc:
+            traffic = (2.0 * pmc["FETCH_SIZE_raw_avg"] + pmc.get("WRITE_SIZE_raw_avg", 0.0)) * 1024.0
+            traffic_src = "profiles/pmc_latest.json"
 
     out = {
         "metric": "rollouts*timesteps/s (randomized-smoothing pass) + iLQR-iters/s",
@@ -166,17 +193,19 @@ def main():
         "ilqr_iters_per_s": args.steps / el_it,
         "ms_per_ilqr_iter": 1e3 * el_it / args.steps,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "smooth_accum_kernel (+ reduce_partials)", "alg_bytes_per_launch": alg_bytes,
-                     "avg_launch_ms": k_mean, "median_launch_ms": k_med},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": "smooth_kernel<PendulumModel, ZERO_ORDER_AB> (sample pass + reduction + solve, "
+                               "one launch)",
+                     "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k_mean,
+                     "avg_event_pair_ms": k_raw, "empty_event_pair_ms": ovh, "median_event_pair_ms": k_med},
     }
     if args.sweep and world == 1:
         sweep = {}
         for Ns in (1000, 100000, 1000000):
-            e, ei, km, kmed = run(Ns, max(20, args.steps // 4), 5)
             st = max(20, args.steps // 4)
+            e, ei, km, kmed, ov = run(Ns, st, 5)
             sweep[str(Ns)] = {"value": Ns * T * st / e, "ilqr_iters_per_s": st / ei,
-                              "kernel_GBps": bytes_per_sample_step * Ns * T / (km * 1e-3) / 1e9}
+                              "kernel_GBps": bytes_per_sample_step * Ns * T / (max(km - ov, 1e-6) * 1e-3) / 1e9}
         out["sweep_N"] = sweep
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:

@@ -100,8 +100,30 @@ int irs_evaluate_cost(int n, int m, int T, const double *x_trj, const double *u_
  *   ZERO_ORDER_B : m(m+1)/2 + m*n                                  (d = n+m)      */
 int irs_sums_len(int model, int mode);
 
-/* Bytes of DEV scratch irs_smooth_accumulate* needs for (T, N).                  */
+/* Bytes of DEV scratch the irs_smooth* calls need for (T, N) (T <= 1024).        */
 size_t irs_smooth_workspace_bytes(int model, int mode, int T, int N);
+
+/* Zeroes the arrival counters at the head of a freshly allocated workspace.  Call
+ * once per allocation; every irs_smooth* call leaves them zero again.  One call in
+ * flight per workspace at a time.                                                */
+int irs_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
+
+/* Whole get_TV_matrices in ONE launch (single-GPU path): sample pass + reduction +
+ * least-squares solve.  Samples SUPPLIED: dx (T,N,n), du (T,N,m) DEV f32 -- what the
+ * reference's `sampling(x_t,u_t,iter)` closure returned at each t, e.g.
+ * examples/pendulum/pendulum_zero_order.py:38-43 ("identical seeds").
+ * Outputs as irs_smooth_accumulate (sums) + irs_smooth_finalize (At,Bt,ct,info).   */
+int irs_smooth(int model, const double *params, int n_params, int mode, int T, int N,
+               const double *x_trj, const double *u_trj, const float *dx, const float *du,
+               double *sums, double *At, double *Bt, double *ct, int *info,
+               void *workspace, size_t workspace_bytes, void *stream);
+
+/* Same with on-device Philox draws (see irs_smooth_accumulate_rng).              */
+int irs_smooth_rng(int model, const double *params, int n_params, int mode, int T, int N,
+                   const double *x_trj, const double *u_trj, const double *std_x,
+                   const double *std_u, uint64_t seed, uint32_t iter, double *sums,
+                   double *At, double *Bt, double *ct, int *info,
+                   void *workspace, size_t workspace_bytes, void *stream);
 
 /* Sample pass, samples SUPPLIED (parity mode; "identical seeds" = the host draws
  * them exactly as the reference's `sampling(x_t,u_t,iter)` closure does, e.g.
@@ -173,6 +195,54 @@ int irs_closed_loop_rollout(int model, const double *params, int n_params, int T
                             const double *K, const double *k, const double *x0,
                             const double *Q, const double *R, const double *xd_trj,
                             double *x_new, double *u_new, double *cost, void *stream);
+
+/* irs_tvlqr_riccati + irs_closed_loop_rollout in ONE launch: everything
+ * IrsLqr.local_descent does after get_TV_matrices (irs_lqr/irs_lqr.py:169-184) plus
+ * evaluate_cost (:121-137) of the new trajectory.  x0 (n) DEV.                    */
+int irs_tvlqr_descent(int model, const double *params, int n_params, int T,
+                      const double *At, const double *Bt, const double *ct,
+                      const double *Q, const double *Qd, const double *R, double alpha_R,
+                      const double *xd_trj, const double *x0, double *K, double *k,
+                      double *x_new, double *u_new, double *cost, int *info, void *stream);
+
+/* ---- Pre-marshalled calls ------------------------------------------------------
+ * The same operations with their arguments packed in a caller-owned struct, so that a
+ * host loop (IrsLqr.iterate, irs_lqr/irs_lqr.py:188-218) pays one pointer-sized FFI
+ * call per launch instead of marshalling ~20 scalars.  Fields have the meaning of the
+ * like-named parameters above.                                                      */
+typedef struct irs_smooth_call {
+    int model, n_params;
+    double params[12];
+    int mode, T, N;
+    const double *x_trj, *u_trj;     /* DEV */
+    const float *dx, *du;            /* DEV; used when use_rng == 0 */
+    int use_rng;                     /* 1: draw on device from std/seed/iter/sample_offset */
+    uint32_t iter;
+    double std_x[32], std_u[16];
+    uint64_t seed, sample_offset;
+    double *sums;                    /* DEV (T,P) out */
+    double *At, *Bt, *ct;            /* DEV out; all NULL = accumulate only */
+    int *info;                       /* DEV (T) out (when At != NULL) */
+    long long n_total;               /* samples per timestep over all devices (solve) */
+    void *workspace;
+    size_t workspace_bytes;
+} irs_smooth_call;
+
+/* irs_smooth / irs_smooth_rng / irs_smooth_accumulate[_rng], by struct.           */
+int irs_smooth_run(const irs_smooth_call *call, void *stream);
+
+typedef struct irs_descent_call {
+    int model, n_params;
+    double params[12];
+    int T;
+    double alpha_R;
+    const double *At, *Bt, *ct, *Q, *Qd, *R, *xd_trj, *x0;   /* DEV */
+    double *K, *k, *x_new, *u_new, *cost;                     /* DEV out */
+    int *info;                                                /* DEV (1) out */
+} irs_descent_call;
+
+/* irs_tvlqr_descent, by struct.                                                    */
+int irs_descent_run(const irs_descent_call *call, void *stream);
 
 #ifdef __cplusplus
 }

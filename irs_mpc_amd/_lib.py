@@ -31,6 +31,14 @@ SIGNATURES = {
     "irs_evaluate_cost": (c_int, [c_int, c_int, c_int, _dp, _dp, _dp, _dp, _dp, _dp, c_void_p]),
     "irs_sums_len": (c_int, [c_int, c_int]),
     "irs_smooth_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "irs_workspace_init": (c_int, [_dp, c_size_t, c_void_p]),
+    "irs_smooth": (c_int, [c_int, POINTER(c_double), c_int, c_int, c_int, c_int, _dp, _dp, _dp, _dp,
+                           _dp, _dp, _dp, _dp, _dp, _dp, c_size_t, c_void_p]),
+    "irs_smooth_rng": (c_int, [c_int, POINTER(c_double), c_int, c_int, c_int, c_int, _dp, _dp,
+                               POINTER(c_double), POINTER(c_double), c_uint64, c_uint32,
+                               _dp, _dp, _dp, _dp, _dp, _dp, c_size_t, c_void_p]),
+    "irs_tvlqr_descent": (c_int, [c_int, POINTER(c_double), c_int, c_int, _dp, _dp, _dp, _dp, _dp, _dp,
+                                  c_double, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, c_void_p]),
     "irs_smooth_accumulate": (c_int, [c_int, POINTER(c_double), c_int, c_int, c_int, c_int, _dp, _dp,
                                       _dp, _dp, _dp, _dp, c_size_t, c_void_p]),
     "irs_smooth_accumulate_rng": (c_int, [c_int, POINTER(c_double), c_int, c_int, c_int, c_int, _dp, _dp,
@@ -47,6 +55,32 @@ SIGNATURES = {
     "irs_closed_loop_rollout": (c_int, [c_int, POINTER(c_double), c_int, c_int, _dp, _dp, _dp, _dp, _dp,
                                         _dp, _dp, _dp, _dp, c_void_p]),
 }
+
+class SmoothCall(ctypes.Structure):
+    """irs_smooth_call (include/irs_hip.h)."""
+    _fields_ = [("model", c_int), ("n_params", c_int), ("params", c_double * 12),
+                ("mode", c_int), ("T", c_int), ("N", c_int),
+                ("x_trj", c_void_p), ("u_trj", c_void_p), ("dx", c_void_p), ("du", c_void_p),
+                ("use_rng", c_int), ("iter", c_uint32),
+                ("std_x", c_double * 32), ("std_u", c_double * 16),
+                ("seed", c_uint64), ("sample_offset", c_uint64),
+                ("sums", c_void_p), ("At", c_void_p), ("Bt", c_void_p), ("ct", c_void_p),
+                ("info", c_void_p), ("n_total", c_longlong),
+                ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
+
+
+class DescentCall(ctypes.Structure):
+    """irs_descent_call (include/irs_hip.h)."""
+    _fields_ = [("model", c_int), ("n_params", c_int), ("params", c_double * 12),
+                ("T", c_int), ("alpha_R", c_double),
+                ("At", c_void_p), ("Bt", c_void_p), ("ct", c_void_p), ("Q", c_void_p), ("Qd", c_void_p),
+                ("R", c_void_p), ("xd_trj", c_void_p), ("x0", c_void_p),
+                ("K", c_void_p), ("k", c_void_p), ("x_new", c_void_p), ("u_new", c_void_p),
+                ("cost", c_void_p), ("info", c_void_p)]
+
+
+SIGNATURES["irs_smooth_run"] = (c_int, [POINTER(SmoothCall), c_void_p])
+SIGNATURES["irs_descent_run"] = (c_int, [POINTER(DescentCall), c_void_p])
 
 _lib = None
 

@@ -17,8 +17,37 @@ struct Dual {
 template <typename T> struct scalar_of { using type = T; };
 template <typename T, int K> struct scalar_of<Dual<T, K>> { using type = T; };
 
-IRS_HD float irs_sin(float x) { return sinf(x); }
-IRS_HD float irs_cos(float x) { return cosf(x); }
+// f32 sine/cosine for the sample pass: branch-free (no large-argument slow path, so the
+// compiler can batch the sample loads around it), ~20 VALU instructions for the pair.
+// Quadrant reduction r = x - q*pi/2 by two FMAs against a hi/lo split of pi/2, then
+// the minimax polynomials on [-pi/4, pi/4].  Absolute error <= ~1.5e-7 for |x| < 1e3
+// (grows like 6e-8*|x|/1e3 beyond); the sample pass is held to an f32 tolerance.
+// sin/cos of q*pi/2 + r for |r| <= pi/4 (+ rounding), q an integer quadrant count.
+IRS_HD void irs_sincos_quadrant(float r, int qi, float& s, float& c);
+
+IRS_HD void irs_sincos(float x, float& s, float& c) {
+    const float q = rintf(x * 0.63661977236758134f);           // 2/pi
+    float r = fmaf(q, -1.57079637050628662f, x);                // pi/2 hi
+    r = fmaf(q, 4.37113900018624283e-8f, r);                    // -(pi/2 lo)
+    irs_sincos_quadrant(r, (int)q, s, c);
+}
+
+IRS_HD void irs_sincos_quadrant(float r, int qi, float& s, float& c) {
+    const float r2 = r * r;
+    float ps = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = fmaf(ps, r2, -1.6666654611e-1f);
+    ps = fmaf(ps * r2, r, r);                                   // sin(r)
+    float pc = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = fmaf(pc, r2, 4.166664568298827e-2f);
+    pc = fmaf(pc * r2, r2, fmaf(r2, -0.5f, 1.0f));              // cos(r)
+    const float ss = (qi & 1) ? pc : ps;
+    const float cc = (qi & 1) ? ps : pc;
+    s = (qi & 2) ? -ss : ss;
+    c = ((qi + 1) & 2) ? -cc : cc;
+}
+IRS_HD void irs_sincos(double x, double& s, double& c) { s = sin(x); c = cos(x); }
+IRS_HD float irs_sin(float x) { float s, c; irs_sincos(x, s, c); return s; }
+IRS_HD float irs_cos(float x) { float s, c; irs_sincos(x, s, c); return c; }
 IRS_HD double irs_sin(double x) { return sin(x); }
 IRS_HD double irs_cos(double x) { return cos(x); }
 
@@ -85,18 +114,11 @@ IRS_DUAL_TK Dual<T, K> operator*(T b, const Dual<T, K>& a) { return a * b; }
 IRS_DUAL_TK Dual<T, K> operator/(const Dual<T, K>& a, T b) { return a * (T(1) / b); }
 IRS_DUAL_TK Dual<T, K> operator/(T b, const Dual<T, K>& a) { return make_const<T, K>(b) / a; }
 
-IRS_DUAL_TK Dual<T, K> irs_sin(const Dual<T, K>& a) {
-    Dual<T, K> r; r.v = irs_sin(a.v);
-    T c = irs_cos(a.v);
+IRS_DUAL_TK void irs_sincos(const Dual<T, K>& a, Dual<T, K>& s, Dual<T, K>& c) {
+    irs_sincos(a.v, s.v, c.v);
 #pragma unroll
-    for (int i = 0; i < K; ++i) r.d[i] = c * a.d[i];
-    return r;
+    for (int i = 0; i < K; ++i) { s.d[i] = c.v * a.d[i]; c.d[i] = -(s.v * a.d[i]); }
 }
-IRS_DUAL_TK Dual<T, K> irs_cos(const Dual<T, K>& a) {
-    Dual<T, K> r; r.v = irs_cos(a.v);
-    T s = -irs_sin(a.v);
-#pragma unroll
-    for (int i = 0; i < K; ++i) r.d[i] = s * a.d[i];
-    return r;
-}
+IRS_DUAL_TK Dual<T, K> irs_sin(const Dual<T, K>& a) { Dual<T, K> s, c; irs_sincos(a, s, c); return s; }
+IRS_DUAL_TK Dual<T, K> irs_cos(const Dual<T, K>& a) { Dual<T, K> s, c; irs_sincos(a, s, c); return c; }
 #undef IRS_DUAL_TK

@@ -41,9 +41,10 @@ struct QuadrotorModel {
         S M0 = L * (uF2 + uF3 - uF0 - uF1);
         S M1 = L * (uF1 + uF2 - uF0 - uF3);
         S M2 = kM * (u[1] + u[3] - u[0] - u[2]);
-        S sr = irs_sin(x[3]), cr = irs_cos(x[3]);
-        S sp = irs_sin(x[4]), cp = irs_cos(x[4]);
-        S sy = irs_sin(x[5]), cy = irs_cos(x[5]);
+        S sr, cr, sp, cp, sy, cy;
+        irs_sincos(x[3], sr, cr);
+        irs_sincos(x[4], sp, cp);
+        irs_sincos(x[5], sy, cy);
         const S rd0 = x[9], rd1 = x[10], rd2 = x[11];
         // :56 xyz_dd = (R_WB F + Fg)/m; only the third column of Rz Ry Rx (:177-183) matters
         T inv_m = T(1) / mass;

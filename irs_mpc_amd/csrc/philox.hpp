@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "dual.hpp"
 
 struct Philox4 { uint32_t v[4]; };
 
@@ -31,9 +32,13 @@ __device__ __forceinline__ void philox_normal4(uint64_t gidx, uint32_t t, uint32
         // (r + 0.5) / 2^32 in (0,1); the f32 rounding of u keeps it inside (0,1]
         float u1 = ((float)r.v[2 * pr] + 0.5f) * 2.3283064365386963e-10f;
         float u2 = ((float)r.v[2 * pr + 1] + 0.5f) * 2.3283064365386963e-10f;
-        float rad = sqrtf(-2.0f * logf(u1));
+        // radius: hardware log2 / sqrt (1 ulp each); angle 2*pi*u2 reduced EXACTLY to a
+        // quadrant (q/4 and u2 - q/4 are exact in f32), then the branch-free polynomials
+        float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __log2f(u1));   // sqrt(-2 ln u1)
+        float q = rintf(4.0f * u2);
+        float r = (u2 - 0.25f * q) * 6.283185307179586f;
         float s, c;
-        sincospif(2.0f * u2, &s, &c);
+        irs_sincos_quadrant(r, (int)q, s, c);
         z[2 * pr] = rad * c;
         z[2 * pr + 1] = rad * s;
     }

@@ -59,11 +59,11 @@ struct WaveReduce<LEN, 6> {
     __device__ __forceinline__ static int base(int) { return 0; }
 };
 
-// Reduces acc[0..P) (padded to PP = irs_reduce_pad(P) with zeros) over the whole
-// workgroup of NW waves and writes the P totals to out[0..P).  `red` is LDS scratch
-// of NW*PP floats.  Fixed summation order: deterministic run to run.
+// Reduces acc[0..P) (padded to PP = irs_reduce_pad(P) with zeros) over each wave and
+// leaves the per-wave totals in LDS: red[w * PP + p], w < NW.  The caller barriers and
+// adds the NW rows in a fixed order (deterministic run to run).
 template <int P, int NW>
-__device__ __forceinline__ void block_reduce_store(float* acc, float* red, float* out) {
+__device__ __forceinline__ void block_reduce_lds(float* acc, float* red) {
     constexpr int PP = irs_reduce_pad(P);
     using WR = WaveReduce<PP, 0>;
     const int tid = threadIdx.x;
@@ -73,12 +73,5 @@ __device__ __forceinline__ void block_reduce_store(float* acc, float* red, float
     if (b >= 0) {
 #pragma unroll
         for (int i = 0; i < WR::FINAL_LEN; ++i) red[wave * PP + b + i] = acc[i];
-    }
-    __syncthreads();
-    for (int p = tid; p < P; p += NW * 64) {
-        float s = red[p];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) s += red[w * PP + p];
-        out[p] = s;
     }
 }

@@ -3,17 +3,29 @@
 //   irs_lqr/irs_lqr_first_order.py:28-54  (FIRST_ORDER)
 //   irs_lqr/quasistatic_dynamics.py:242-266 (ZERO_ORDER_B, u-only noise)
 //   irs_lqr/irs_lqr_exact.py:15-31        (exact)
-// as a streaming map-reduce over the (T x N) grid of independent one-step samples.
+// as ONE launch: a streaming map-reduce over the (T x N) grid of independent one-step
+// samples whose last-arriving workgroup per timestep finishes the job.
 //
-//   pass 1  smooth_accum_kernel   grid (nblk, T) x 256 threads.  Each lane streams
-//           its samples' z=[dx|du] (f32, vector loads, consecutive lanes read
-//           consecutive records), evaluates the model functor in f32, accumulates
-//           the P sufficient statistics in registers, then the workgroup reduces
-//           them with wave shuffles + one LDS hop -> partial[t][blk][P] (f32).
-//   pass 2  reduce_partials_kernel  partial -> sums[t][P] in f64, fixed order.
-//           (`sums` is what several GPUs all-reduce.)
-//   pass 3  smooth_finalize_kernel  one wave per timestep: Jacobi-scaled Cholesky of
-//           the Gram matrix in f64 -> A_t, B_t;  c_t = f(x_t,u_t) - A_t x_t - B_t u_t.
+//   smooth_kernel   grid (nblk, T) x 256 threads.
+//     1. every lane streams its samples' z=[dx|du] (f32, vector loads, consecutive
+//        lanes read consecutive records), evaluates the model functor in f32 and
+//        accumulates the P sufficient statistics of its timestep in registers;
+//     2. the workgroup transpose-reduces them with wave shuffles + one LDS hop and
+//        publishes its P partial sums (write-through stores), then takes a ticket on
+//        the timestep's arrival counter;
+//     3. the workgroup that draws the last ticket of timestep t re-reads the nblk
+//        partials in a FIXED order (f64) -> sums[t][P]   (deterministic: no float
+//        atomics, the arrival order never changes the summation order);
+//     4. (single-GPU path) its first wave solves the Jacobi-scaled normal equations
+//        by Cholesky in f64 -> A_t, B_t and c_t = f(x_t,u_t) - A_t x_t - B_t u_t.
+//   With several GPUs step 4 is a separate launch (smooth_finalize_kernel) after the
+//   all-reduce of `sums`.
+//
+// Inter-workgroup hand-off follows cdna_hip_programming.md Guideline 16: partials are
+// stored sc1 (agent-scope relaxed atomic stores), every storing wave drains vmcnt, the
+// workgroup barriers, one lane adds to the counter; the consumer does one agent-scope
+// acquire + vmcnt(0) + barrier before any load of the partials.
+#include <cstdlib>
 #include "irs_common.hpp"
 #include "philox.hpp"
 #include "reduce.hpp"
@@ -22,6 +34,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
+constexpr int kCounterBytes = 4096;   // head of the workspace: arrival counters
 
 template <class Model, int MODE>
 struct SmoothTraits {
@@ -32,6 +45,8 @@ struct SmoothTraits {
     static constexpr int NG = NZ * (NZ + 1) / 2;
     static constexpr int P = (MODE == IRS_SMOOTH_FIRST_ORDER) ? n * d : NG + NZ * n;
     static constexpr int PP = irs_reduce_pad(P);
+    // last-arriver reduction: NGRP groups of P lanes each sum a strided subset of blocks
+    static constexpr int NGRP = (P >= kBlock) ? 1 : kBlock / P;
 };
 
 struct SmoothArgs {
@@ -44,8 +59,16 @@ struct SmoothArgs {
     unsigned long long seed;
     unsigned long long sample_offset;
     unsigned int iter;
-    int T, N, chunk, nblk;
-    float* partial;
+    int T, N, chunk, nblk, block;
+    int* counters;     // (T) arrival counters, zero between calls
+    float* partial;    // (T, nblk, P)
+    double* sums;      // (T, P) out
+    // finalize outputs (fused path only)
+    double* At;
+    double* Bt;
+    double* ct;
+    int* info;
+    double n_total;
 };
 
 template <int K>
@@ -68,11 +91,208 @@ __device__ __forceinline__ void load_row(const float* __restrict__ ptr, float* o
     }
 }
 
-template <class Model, int MODE, bool RNG>
-__global__ __launch_bounds__(kBlock) void smooth_accum_kernel(SmoothArgs a) {
+// Orders this wave's LDS traffic (the LDS executes one wave's operations in issue
+// order; this only stops the compiler from moving them) -- a barrier for ONE wave.
+__device__ __forceinline__ void wave_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <class Model, int MODE>
+struct FinalizeLds {
+    using TR = SmoothTraits<Model, MODE>;
+    double G[TR::NZ][TR::NZ + 1];
+    double H[TR::NZ][TR::n];
+    double sc[TR::NZ];
+    double AB[TR::n][TR::d];
+    int bad;
+};
+
+// Solve step for timestep t, executed by ONE wave (lane = 0..63).  S: the P f64 sums of
+// the timestep (LDS or global).
+template <class Model, int MODE>
+__device__ __forceinline__ void finalize_timestep(const ModelParams& p, const double* x_trj,
+                                                  const double* u_trj, const double* S, double n_total,
+                                                  int t, int lane, FinalizeLds<Model, MODE>& L,
+                                                  double* At, double* Bt, double* ct, int* info) {
     using TR = SmoothTraits<Model, MODE>;
     constexpr int n = TR::n, m = TR::m, d = TR::d, NZ = TR::NZ, Z0 = TR::Z0;
-    __shared__ float red[kWaves * TR::PP];
+
+    double x[n], u[m], f[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) x[i] = x_trj[(size_t)t * n + i];
+#pragma unroll
+    for (int j = 0; j < m; ++j) u[j] = u_trj[(size_t)t * m + j];
+
+    if (lane == 0) L.bad = 0;
+    if constexpr (MODE == IRS_SMOOTH_FIRST_ORDER) {
+        Model::template step<double>(p, x, u, f);
+        for (int q = lane; q < n * d; q += 64) L.AB[q / d][q % d] = S[q] / n_total;
+    } else {
+        if constexpr (MODE == IRS_SMOOTH_ZERO_ORDER_B) {
+            // A = exact Jacobian at the nominal point (quasistatic_dynamics.py:254-256)
+            double J[n * d];
+            model_jacobian<Model, double>(p, x, u, f, J);
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < n; ++i)
+#pragma unroll
+                    for (int k = 0; k < n; ++k) L.AB[i][k] = J[i * d + k];
+            }
+        } else {
+            Model::template step<double>(p, x, u, f);
+        }
+        if constexpr (NZ <= 4) {
+            // tiny system: every lane solves it in registers (no LDS round trips)
+            double g[NZ][NZ], h[NZ][n], scl[NZ], lo[NZ][NZ];
+            int badr = 0;
+#pragma unroll
+            for (int i = 0; i < NZ; ++i)
+#pragma unroll
+                for (int j = i; j < NZ; ++j) {
+                    g[i][j] = S[i * NZ - i * (i - 1) / 2 + (j - i)];
+                    g[j][i] = g[i][j];
+                }
+#pragma unroll
+            for (int i = 0; i < NZ; ++i)
+#pragma unroll
+                for (int k = 0; k < n; ++k) h[i][k] = S[TR::NG + i * n + k];
+#pragma unroll
+            for (int i = 0; i < NZ; ++i) {
+                bool pos = g[i][i] > 0.0;
+                scl[i] = pos ? 1.0 / sqrt(g[i][i]) : 0.0;
+                if (!pos && badr == 0) badr = i + 1;
+            }
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) {
+                double djj = g[j][j] * scl[j] * scl[j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) djj -= lo[j][k] * lo[j][k];
+                if (!(djj > 1e-14)) {
+                    if (badr == 0) badr = j + 1;
+                    djj = 1.0;
+                }
+                lo[j][j] = sqrt(djj);
+                double il = 1.0 / lo[j][j];
+#pragma unroll
+                for (int i = j + 1; i < NZ; ++i) {
+                    double s = g[i][j] * scl[i] * scl[j];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) s -= lo[i][k] * lo[j][k];
+                    lo[i][j] = s * il;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < n; ++k) {
+                double y[NZ];
+#pragma unroll
+                for (int i = 0; i < NZ; ++i) {
+                    double s = h[i][k] * scl[i];
+#pragma unroll
+                    for (int l = 0; l < i; ++l) s -= lo[i][l] * y[l];
+                    y[i] = s / lo[i][i];
+                }
+#pragma unroll
+                for (int i = NZ - 1; i >= 0; --i) {
+                    double s = y[i];
+#pragma unroll
+                    for (int l = i + 1; l < NZ; ++l) s -= lo[l][i] * y[l];
+                    y[i] = s / lo[i][i];
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < NZ; ++i) L.AB[k][Z0 + i] = y[i] * scl[i];
+                }
+            }
+            if (lane == 0 && badr != 0) L.bad = badr;
+        } else {
+        // unpack the upper-triangular Gram and the cross term
+        for (int q = lane; q < NZ * NZ; q += 64) {
+            int i = q / NZ, j = q % NZ;
+            int r = i < j ? i : j, c = i < j ? j : i;
+            L.G[i][j] = S[r * NZ - r * (r - 1) / 2 + (c - r)];
+        }
+        for (int q = lane; q < NZ * n; q += 64) L.H[q / n][q % n] = S[TR::NG + q];
+        wave_sync();
+        // Jacobi scaling: G' = D G D, H' = D H, D = diag(G)^-1/2
+        if (lane < NZ) {
+            double g = L.G[lane][lane];
+            L.sc[lane] = g > 0.0 ? 1.0 / sqrt(g) : 0.0;
+            if (!(g > 0.0)) L.bad = lane + 1;
+        }
+        wave_sync();
+        for (int q = lane; q < NZ * NZ; q += 64) L.G[q / NZ][q % NZ] *= L.sc[q / NZ] * L.sc[q % NZ];
+        for (int q = lane; q < NZ * n; q += 64) L.H[q / n][q % n] *= L.sc[q / n];
+        wave_sync();
+        // right-looking Cholesky, lower triangle in place
+        for (int j = 0; j < NZ; ++j) {
+            double djj = L.G[j][j];
+            if (!(djj > 1e-14)) {
+                if (lane == 0 && L.bad == 0) L.bad = j + 1;
+                djj = 1.0;
+            }
+            double l = sqrt(djj);
+            double il = 1.0 / l;
+            wave_sync();
+            if (lane == j) L.G[j][j] = l;
+            if (lane > j && lane < NZ) L.G[lane][j] *= il;
+            wave_sync();
+            // trailing update: element (r,c), j < c <= r < NZ
+            for (int q = lane; q < NZ * NZ; q += 64) {
+                int r = q / NZ, c = q % NZ;
+                if (c > j && r >= c) L.G[r][c] -= L.G[r][j] * L.G[c][j];
+            }
+            wave_sync();
+        }
+        // one lane per right-hand side: L y = h, L' w = y;  AB[k][Z0+i] = sc_i w_i
+        if (lane < n) {
+            double y[NZ];
+#pragma unroll
+            for (int i = 0; i < NZ; ++i) {
+                double s = L.H[i][lane];
+#pragma unroll
+                for (int k = 0; k < i; ++k) s -= L.G[i][k] * y[k];
+                y[i] = s / L.G[i][i];
+            }
+#pragma unroll
+            for (int i = NZ - 1; i >= 0; --i) {
+                double s = y[i];
+#pragma unroll
+                for (int k = i + 1; k < NZ; ++k) s -= L.G[k][i] * y[k];
+                y[i] = s / L.G[i][i];
+            }
+#pragma unroll
+            for (int i = 0; i < NZ; ++i) L.AB[lane][Z0 + i] = y[i] * L.sc[i];
+        }
+        }  // NZ > 4
+    }
+    wave_sync();
+    for (int q = lane; q < n * n; q += 64) At[(size_t)t * n * n + q] = L.AB[q / n][q % n];
+    for (int q = lane; q < n * m; q += 64) Bt[(size_t)t * n * m + q] = L.AB[q / m][n + q % m];
+    if (lane < n) {
+        double c = f[0];
+#pragma unroll
+        for (int i = 0; i < n; ++i) c = (i == lane) ? f[i] : c;
+#pragma unroll
+        for (int i = 0; i < n; ++i) c -= L.AB[lane][i] * x[i];
+#pragma unroll
+        for (int j = 0; j < m; ++j) c -= L.AB[lane][n + j] * u[j];
+        ct[(size_t)t * n + lane] = c;
+    }
+    if (lane == 0) info[t] = L.bad;
+}
+
+template <class Model, int MODE, bool RNG, bool FUSE, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
+    using TR = SmoothTraits<Model, MODE>;
+    constexpr int n = TR::n, m = TR::m, d = TR::d, NZ = TR::NZ, Z0 = TR::Z0, P = TR::P;
+    constexpr int NW = BLOCK / 64;
+    constexpr int P4 = (P + 3) / 4 * 4;     // row stride of the partial buffer (16-byte rows)
+    __shared__ float red[NW * TR::PP];
+    __shared__ double red64[TR::NGRP * P];
+    __shared__ double tot[P];
+    __shared__ FinalizeLds<Model, MODE> fin;
+    __shared__ int s_ticket;
 
     const int t = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
 
@@ -88,198 +308,174 @@ __global__ __launch_bounds__(kBlock) void smooth_accum_kernel(SmoothArgs a) {
 #pragma unroll
     for (int i = 0; i < TR::PP; ++i) acc[i] = 0.f;
 
+    // Sample loop.  U samples per lane are loaded together (independent loads in
+    // flight), then evaluated; out-of-range slots are clamped to a valid address and
+    // zeroed (a zero perturbation contributes exactly nothing to the zero-order sums).
     const int s_end = min(a.N, (blk + 1) * a.chunk);
-    for (int s = blk * a.chunk + tid; s < s_end; s += kBlock) {
-        float z[d];
-        if constexpr (RNG) {
-            constexpr int j0 = Z0 / 4;
-            const unsigned long long gidx = a.sample_offset + (unsigned long long)s;
+    constexpr int U = (TR::PP <= 64 && !RNG) ? 4 : 1;
+    for (int s0 = blk * a.chunk + tid; s0 < s_end; s0 += BLOCK * U) {
+        float zz[U][d];
+        bool valid[U];
 #pragma unroll
-            for (int j = j0; j < (d + 3) / 4; ++j) {
-                float g[4];
-                philox_normal4(gidx, (unsigned)t, (unsigned)j, a.iter, a.seed, g);
+        for (int uu = 0; uu < U; ++uu) {
+            const int s = s0 + uu * BLOCK;
+            valid[uu] = s < s_end;
+            if constexpr (RNG) {
+                constexpr int j0 = Z0 / 4;
+                const unsigned long long gidx = a.sample_offset + (unsigned long long)s;
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (4 * j + c < d) z[4 * j + c] = g[c] * a.std[4 * j + c];
+                for (int j = j0; j < (d + 3) / 4; ++j) {
+                    float g[4];
+                    philox_normal4(gidx, (unsigned)t, (unsigned)j, a.iter, a.seed, g);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (4 * j + c < d) zz[uu][4 * j + c] = g[c] * a.std[4 * j + c];
+                }
+#pragma unroll
+                for (int i = 0; i < Z0; ++i) zz[uu][i] = 0.f;
+            } else {
+                const size_t row = (size_t)t * a.N + (valid[uu] ? s : s_end - 1);
+                if constexpr (Z0 == 0) load_row<n>(a.dx + row * n, zz[uu]);
+                else {
+#pragma unroll
+                    for (int i = 0; i < n; ++i) zz[uu][i] = 0.f;
+                }
+                load_row<m>(a.du + row * m, zz[uu] + n);
             }
-#pragma unroll
-            for (int i = 0; i < Z0; ++i) z[i] = 0.f;
-        } else {
-            const size_t row = (size_t)t * a.N + s;
-            if constexpr (Z0 == 0) load_row<n>(a.dx + row * n, z);
-            else {
-#pragma unroll
-                for (int i = 0; i < n; ++i) z[i] = 0.f;
-            }
-            load_row<m>(a.du + row * m, z + n);
         }
-        float xs[n], us[m], fx[n];
 #pragma unroll
-        for (int i = 0; i < n; ++i) xs[i] = xb[i] + z[i];
+        for (int uu = 0; uu < U; ++uu) {
+            float z[d];
 #pragma unroll
-        for (int j = 0; j < m; ++j) us[j] = ub[j] + z[n + j];
+            for (int i = 0; i < d; ++i) z[i] = (U == 1 || valid[uu]) ? zz[uu][i] : 0.f;
+            float xs[n], us[m], fx[n];
+#pragma unroll
+            for (int i = 0; i < n; ++i) xs[i] = xb[i] + z[i];
+#pragma unroll
+            for (int j = 0; j < m; ++j) us[j] = ub[j] + z[n + j];
 
-        if constexpr (MODE == IRS_SMOOTH_FIRST_ORDER) {
-            float J[n * d];
-            model_jacobian<Model, float>(a.p, xs, us, fx, J);
+            if constexpr (MODE == IRS_SMOOTH_FIRST_ORDER) {
+                float J[n * d];
+                model_jacobian<Model, float>(a.p, xs, us, fx, J);
+                const float w = (U == 1 || valid[uu]) ? 1.f : 0.f;
 #pragma unroll
-            for (int q = 0; q < n * d; ++q) acc[q] += J[q];
-        } else {
-            Model::template step<float>(a.p, xs, us, fx);
-            float df[n];
+                for (int q = 0; q < n * d; ++q) acc[q] = fmaf(w, J[q], acc[q]);
+            } else {
+                Model::template step<float>(a.p, xs, us, fx);
+                float df[n];
 #pragma unroll
-            for (int k = 0; k < n; ++k) df[k] = fx[k] - f0[k];
-            int q = 0;
+                for (int k = 0; k < n; ++k) df[k] = fx[k] - f0[k];
+                int q = 0;
 #pragma unroll
-            for (int i = 0; i < NZ; ++i)
+                for (int i = 0; i < NZ; ++i)
 #pragma unroll
-                for (int j = i; j < NZ; ++j) { acc[q] = fmaf(z[Z0 + i], z[Z0 + j], acc[q]); ++q; }
+                    for (int j = i; j < NZ; ++j) { acc[q] = fmaf(z[Z0 + i], z[Z0 + j], acc[q]); ++q; }
 #pragma unroll
-            for (int i = 0; i < NZ; ++i)
+                for (int i = 0; i < NZ; ++i)
 #pragma unroll
-                for (int k = 0; k < n; ++k) { acc[q] = fmaf(z[Z0 + i], df[k], acc[q]); ++q; }
+                    for (int k = 0; k < n; ++k) { acc[q] = fmaf(z[Z0 + i], df[k], acc[q]); ++q; }
+            }
         }
     }
-    block_reduce_store<TR::P, kWaves>(acc, red, a.partial + ((size_t)t * a.nblk + blk) * TR::P);
-}
 
-// partial (T, nblk, P) f32 -> sums (T, P) f64, fixed order over blk.
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, double* __restrict__ sums,
-                                       int nblk, int P) {
-    const int t = blockIdx.y;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    const float* src = partial + (size_t)t * nblk * P + p;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)src[(size_t)b * P];
-    sums[(size_t)t * P + p] = s;
-}
+    // ---- workgroup reduction: registers -> shuffles -> LDS -------------------------
+    block_reduce_lds<P, NW>(acc, red);
+    __syncthreads();
 
-struct FinalizeArgs {
-    ModelParams p;
-    const double* x_trj;
-    const double* u_trj;
-    const double* sums;
-    double* At;
-    double* Bt;
-    double* ct;
-    int* info;
-    double n_total;
-    int T;
-};
-
-// One wave (64 lanes) per timestep.
-template <class Model, int MODE>
-__global__ __launch_bounds__(64) void smooth_finalize_kernel(FinalizeArgs a) {
-    using TR = SmoothTraits<Model, MODE>;
-    constexpr int n = TR::n, m = TR::m, d = TR::d, NZ = TR::NZ, Z0 = TR::Z0;
-    __shared__ double G[NZ][NZ + 1];
-    __shared__ double H[NZ][n];
-    __shared__ double sc[NZ];
-    __shared__ double AB[n][d];
-    __shared__ int bad;
-
-    const int t = blockIdx.x, lane = threadIdx.x;
-    const double* S = a.sums + (size_t)t * TR::P;
-
-    double x[n], u[m], f[n];
+    const int nblk = a.nblk;
+    if (nblk == 1) {
+        // the only workgroup of this timestep: totals straight from LDS
+        for (int q = tid; q < P; q += BLOCK) {
+            float s = red[q];
 #pragma unroll
-    for (int i = 0; i < n; ++i) x[i] = a.x_trj[(size_t)t * n + i];
+            for (int w = 1; w < NW; ++w) s += red[w * TR::PP + q];
+            tot[q] = (double)s;
+        }
+    } else if constexpr (BLOCK == kBlock) {
+        // publish this workgroup's partial sums: 16-byte write-through (sc1) stores, one
+        // row of P4 floats per workgroup (few wide fabric writes instead of P narrow ones)
+        for (int q = tid; q < P; q += BLOCK) {
+            float s = red[q];
 #pragma unroll
-    for (int j = 0; j < m; ++j) u[j] = a.u_trj[(size_t)t * m + j];
-
-    if constexpr (MODE == IRS_SMOOTH_FIRST_ORDER) {
-        Model::template step<double>(a.p, x, u, f);
-        for (int q = lane; q < n * d; q += 64) AB[q / d][q % d] = S[q] / a.n_total;
-        if (lane == 0) bad = 0;
-    } else {
-        if constexpr (MODE == IRS_SMOOTH_ZERO_ORDER_B) {
-            // A = exact Jacobian at the nominal point (quasistatic_dynamics.py:254-256)
-            double J[n * d];
-            model_jacobian<Model, double>(a.p, x, u, f, J);
-            if (lane == 0) {
-#pragma unroll
-                for (int i = 0; i < n; ++i)
-#pragma unroll
-                    for (int k = 0; k < n; ++k) AB[i][k] = J[i * d + k];
+            for (int w = 1; w < NW; ++w) s += red[w * TR::PP + q];
+            red[q] = s;                       // column q is touched by this lane only
+        }
+        __syncthreads();
+        {
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const unsigned bytes = (unsigned)((size_t)a.T * nblk * P4 * sizeof(float));
+            __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.partial, 0, bytes, 0x00020000);
+            const unsigned row = (unsigned)(((size_t)t * nblk + blk) * P4 * sizeof(float));
+            for (int q4 = tid; q4 < P4 / 4; q4 += BLOCK) {
+                u32x4 v;
+                v.x = __float_as_uint(red[4 * q4]);
+                v.y = __float_as_uint(red[4 * q4 + 1]);
+                v.z = __float_as_uint(red[4 * q4 + 2]);
+                v.w = __float_as_uint(red[4 * q4 + 3]);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, row + 16u * q4, 0, 16 /* sc1 */);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+            s_ticket = __hip_atomic_fetch_add(a.counters + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_ticket != nblk - 1) return;       // uniform over the workgroup
+        // ---- last arriver of timestep t ------------------------------------------
+        if (tid == 0) {
+            __hip_atomic_store(a.counters + t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const float* src = a.partial + (size_t)t * nblk * P4;
+        if constexpr (P >= kBlock) {
+            // plain loads are valid behind the acquire above; unrolled so that the
+            // (independent) loads are in flight together, summed in a fixed order
+            for (int q = tid; q < P; q += BLOCK) {
+                double s = 0.0;
+#pragma unroll 8
+                for (int b = 0; b < nblk; ++b) s += (double)src[(size_t)b * P4 + q];
+                tot[q] = s;
             }
         } else {
-            Model::template step<double>(a.p, x, u, f);
-        }
-        if (lane == 0) bad = 0;
-        // unpack the upper-triangular Gram and the cross term
-        for (int q = lane; q < NZ * NZ; q += 64) {
-            int i = q / NZ, j = q % NZ;
-            int r = i < j ? i : j, c = i < j ? j : i;
-            G[i][j] = S[r * NZ - r * (r - 1) / 2 + (c - r)];
-        }
-        for (int q = lane; q < NZ * n; q += 64) H[q / n][q % n] = S[TR::NG + q];
-        __syncthreads();
-        // Jacobi scaling: G' = D G D, H' = D H, D = diag(G)^-1/2
-        if (lane < NZ) {
-            double g = G[lane][lane];
-            sc[lane] = g > 0.0 ? 1.0 / sqrt(g) : 0.0;
-            if (!(g > 0.0)) bad = lane + 1;
-        }
-        __syncthreads();
-        for (int q = lane; q < NZ * NZ; q += 64) G[q / NZ][q % NZ] *= sc[q / NZ] * sc[q % NZ];
-        for (int q = lane; q < NZ * n; q += 64) H[q / n][q % n] *= sc[q / n];
-        __syncthreads();
-        // right-looking Cholesky, lower triangle in place
-        for (int j = 0; j < NZ; ++j) {
-            double djj = G[j][j];
-            if (!(djj > 1e-14)) {
-                if (lane == 0 && bad == 0) bad = j + 1;
-                djj = 1.0;
-            }
-            double l = sqrt(djj);
-            __syncthreads();
-            if (lane == j) G[j][j] = l;
-            if (lane > j && lane < NZ) G[lane][j] /= l;
-            __syncthreads();
-            // trailing update: element (r,c), j < c <= r < NZ
-            for (int q = lane; q < NZ * NZ; q += 64) {
-                int r = q / NZ, c = q % NZ;
-                if (c > j && r >= c) G[r][c] -= G[r][j] * G[c][j];
+            const int g = tid / P, q = tid % P;
+            if (g < TR::NGRP) {
+                double s = 0.0;
+#pragma unroll 4
+                for (int b = g; b < nblk; b += TR::NGRP) s += (double)src[(size_t)b * P4 + q];
+                red64[g * P + q] = s;
             }
             __syncthreads();
-        }
-        // one lane per right-hand side: L y = h, L' w = y;  AB[k][Z0+i] = sc_i w_i
-        if (lane < n) {
-            double y[NZ];
-#pragma unroll
-            for (int i = 0; i < NZ; ++i) {
-                double s = H[i][lane];
-                for (int k = 0; k < i; ++k) s -= G[i][k] * y[k];
-                y[i] = s / G[i][i];
+            if (tid < P) {
+                double s = red64[tid];
+                for (int gg = 1; gg < TR::NGRP; ++gg) s += red64[gg * P + tid];
+                tot[tid] = s;
             }
-#pragma unroll
-            for (int i = NZ - 1; i >= 0; --i) {
-                double s = y[i];
-                for (int k = i + 1; k < NZ; ++k) s -= G[k][i] * y[k];
-                y[i] = s / G[i][i];
-            }
-#pragma unroll
-            for (int i = 0; i < NZ; ++i) AB[lane][Z0 + i] = y[i] * sc[i];
         }
     }
     __syncthreads();
-    for (int q = lane; q < n * n; q += 64) a.At[(size_t)t * n * n + q] = AB[q / n][q % n];
-    for (int q = lane; q < n * m; q += 64) a.Bt[(size_t)t * n * m + q] = AB[q / m][n + q % m];
-    if (lane < n) {
-        double c = f[0];
-#pragma unroll
-        for (int i = 0; i < n; ++i) c = (i == lane) ? f[i] : c;
-        for (int i = 0; i < n; ++i) c -= AB[lane][i] * x[i];
-        for (int j = 0; j < m; ++j) c -= AB[lane][n + j] * u[j];
-        a.ct[(size_t)t * n + lane] = c;
+    for (int q = tid; q < P; q += BLOCK) a.sums[(size_t)t * P + q] = tot[q];
+    if constexpr (FUSE) {
+        if (tid < 64)
+            finalize_timestep<Model, MODE>(a.p, a.x_trj, a.u_trj, tot, a.n_total, t, tid, fin, a.At, a.Bt,
+                                           a.ct, a.info);
     }
-    if (lane == 0) a.info[t] = bad;
+}
+
+// Stand-alone solve (after an all-reduce of `sums`): one wave per timestep.
+template <class Model, int MODE>
+__global__ __launch_bounds__(64) void smooth_finalize_kernel(SmoothArgs a) {
+    __shared__ FinalizeLds<Model, MODE> fin;
+    const int t = blockIdx.x;
+    finalize_timestep<Model, MODE>(a.p, a.x_trj, a.u_trj, a.sums + (size_t)t * SmoothTraits<Model, MODE>::P,
+                                   a.n_total, t, threadIdx.x, fin, a.At, a.Bt, a.ct, a.info);
 }
 
 template <class Model>
-__global__ __launch_bounds__(64) void exact_linearize_kernel(ModelParams p, const double* x_trj, const double* u_trj,
-                                       double* At, double* Bt, double* ct, int T) {
+__global__ __launch_bounds__(64) void exact_linearize_kernel(ModelParams p, const double* x_trj,
+                                                             const double* u_trj, double* At, double* Bt,
+                                                             double* ct, int T) {
     constexpr int n = Model::NX, m = Model::NU, d = n + m;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
@@ -323,11 +519,48 @@ __global__ void rng_samples_kernel(float* dx, float* du, SmoothArgs a) {
     for (int j = 0; j < m; ++j) du[row * m + j] = z[n + j] * a.std[n + j];
 }
 
-void plan_grid(int T, int N, int* chunk, int* nblk) {
-    // >= 1 sample per lane, and no more workgroups than ~16 per CU across the grid
-    int max_blk = 4096 / (T > 0 ? T : 1);
+// Planner knobs (environment overrides are for tuning experiments only).
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    int v = e ? atoi(e) : dflt;
+    return v < 1 ? 1 : v;
+}
+int tune_spt() { static int v = env_int("IRS_SPT", 32); return v; }                 // samples per lane aimed for
+int tune_single_max() { static int v = env_int("IRS_SINGLE_MAX", 16384); return v; } // <= : one WG per t
+int tune_max_wg() { static int v = env_int("IRS_MAX_WG", 1024); return v; }         // grid cap, light kernels
+int tune_max_wg_heavy() { static int v = env_int("IRS_MAX_WG_HEAVY", 256); return v; }  // 1 wave/SIMD kernels
+int tune_min_wg() { static int v = env_int("IRS_MIN_WG", 256); return v; }          // fill the CUs
+
+constexpr int kBigBlock = 1024;
+
+// Chooses the launch geometry for (T, N).  `light` = the kernel's accumulators fit a
+// 1024-thread workgroup (PP <= 64).  Measured on MI355X (profiles/): every extra
+// workgroup costs more (its hand-off: write-through stores + ticket) than it gains in
+// streaming parallelism once the CUs are covered, so grids stay SMALL:
+//  * light, samples supplied, N <= tune_single_max(): ONE 1024-thread workgroup per
+//    timestep -- no inter-workgroup hand-off at all;
+//  * otherwise 256-thread workgroups, ~tune_spt() samples per lane, at least enough
+//    workgroups to cover the CUs (while each lane still has >= 4 samples) and at most
+//    ~4 per CU (light kernels) or 1 per CU (kernels that hold 1 wave per SIMD).
+void plan_grid(int T, int N, bool light, bool rng, int* chunk, int* nblk, int* block) {
+    if (light && !rng && N <= tune_single_max()) {
+        *block = kBigBlock;
+        *nblk = 1;
+        *chunk = (N + kBigBlock - 1) / kBigBlock * kBigBlock;
+        return;
+    }
+    *block = kBlock;
+    if (T < 1) T = 1;
+    const int spt = tune_spt();
+    int nb = (N + kBlock * spt - 1) / (kBlock * spt);
+    int fill = (tune_min_wg() + T - 1) / T;               // blocks per t that cover the CUs
+    int by4 = (N + kBlock * 4 - 1) / (kBlock * 4);        // ... keeping >= 4 samples per lane
+    if (fill > by4) fill = by4;
+    if (nb < fill) nb = fill;
+    // heavy kernels: 1 workgroup per CU, 2 once there is enough work to hide the tail
+    const int heavy_cap = tune_max_wg_heavy() * ((long long)N * T >= 2000000 ? 2 : 1);
+    int max_blk = (light ? tune_max_wg() : heavy_cap) / T;
     if (max_blk < 1) max_blk = 1;
-    int nb = (N + kBlock - 1) / kBlock;
     if (nb > max_blk) nb = max_blk;
     if (nb < 1) nb = 1;
     int c = (N + nb - 1) / nb;
@@ -350,26 +583,39 @@ int sums_len_m(int mode) {
     return -1;
 }
 
-template <class Model, bool RNG>
-int launch_accum(int mode, const SmoothArgs& a, hipStream_t st) {
-    dim3 grid(a.nblk, a.T), block(kBlock);
+template <class Model, int MODE, int BLOCK>
+void launch_smooth_b(const SmoothArgs& a, bool rng, bool fuse, hipStream_t st) {
+    dim3 grid(a.nblk, a.T), block(BLOCK);
+    if (rng) {
+        if (fuse) hipLaunchKernelGGL((smooth_kernel<Model, MODE, true, true, BLOCK>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((smooth_kernel<Model, MODE, true, false, BLOCK>), grid, block, 0, st, a);
+    } else {
+        if (fuse) hipLaunchKernelGGL((smooth_kernel<Model, MODE, false, true, BLOCK>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((smooth_kernel<Model, MODE, false, false, BLOCK>), grid, block, 0, st, a);
+    }
+}
+
+template <class Model, int MODE>
+void launch_smooth_m(const SmoothArgs& a, bool rng, bool fuse, hipStream_t st) {
+    if constexpr (SmoothTraits<Model, MODE>::PP <= 64) {
+        if (a.block == kBigBlock) { launch_smooth_b<Model, MODE, kBigBlock>(a, rng, fuse, st); return; }
+    }
+    launch_smooth_b<Model, MODE, kBlock>(a, rng, fuse, st);
+}
+
+template <class Model>
+int launch_smooth(int mode, const SmoothArgs& a, bool rng, bool fuse, hipStream_t st) {
     switch (mode) {
-        case IRS_SMOOTH_ZERO_ORDER_AB:
-            hipLaunchKernelGGL((smooth_accum_kernel<Model, IRS_SMOOTH_ZERO_ORDER_AB, RNG>), grid, block, 0, st, a);
-            break;
-        case IRS_SMOOTH_FIRST_ORDER:
-            hipLaunchKernelGGL((smooth_accum_kernel<Model, IRS_SMOOTH_FIRST_ORDER, RNG>), grid, block, 0, st, a);
-            break;
-        case IRS_SMOOTH_ZERO_ORDER_B:
-            hipLaunchKernelGGL((smooth_accum_kernel<Model, IRS_SMOOTH_ZERO_ORDER_B, RNG>), grid, block, 0, st, a);
-            break;
+        case IRS_SMOOTH_ZERO_ORDER_AB: launch_smooth_m<Model, IRS_SMOOTH_ZERO_ORDER_AB>(a, rng, fuse, st); break;
+        case IRS_SMOOTH_FIRST_ORDER: launch_smooth_m<Model, IRS_SMOOTH_FIRST_ORDER>(a, rng, fuse, st); break;
+        case IRS_SMOOTH_ZERO_ORDER_B: launch_smooth_m<Model, IRS_SMOOTH_ZERO_ORDER_B>(a, rng, fuse, st); break;
         default: return IRS_ERR_UNSUPPORTED;
     }
     return IRS_OK;
 }
 
 template <class Model>
-int launch_finalize(int mode, const FinalizeArgs& a, hipStream_t st) {
+int launch_finalize(int mode, const SmoothArgs& a, hipStream_t st) {
     dim3 grid(a.T), block(64);
     switch (mode) {
         case IRS_SMOOTH_ZERO_ORDER_AB:
@@ -386,33 +632,61 @@ int launch_finalize(int mode, const FinalizeArgs& a, hipStream_t st) {
     return IRS_OK;
 }
 
-int accumulate_common(int model, const double* params, int n_params, int mode, int T, int N,
-                      const double* x_trj, const double* u_trj, SmoothArgs& a, bool rng,
-                      double* sums, void* workspace, size_t workspace_bytes, void* stream) {
+struct SmoothOut {   // finalize outputs; all null = accumulate only
+    double* At; double* Bt; double* ct; int* info; long long n_total;
+};
+
+int smooth_common(int model, const double* params, int n_params, int mode, int T, int N,
+                  const double* x_trj, const double* u_trj, SmoothArgs& a, bool rng, double* sums,
+                  const SmoothOut* out, void* workspace, size_t workspace_bytes, void* stream) {
     IRS_CHECK_ARG(T > 0 && N > 0, "T and N must be positive");
     IRS_CHECK_ARG(x_trj && u_trj && sums && workspace, "null pointer");
     IRS_CHECK_ARG(mode >= 0 && mode <= 2, "unknown smoothing mode");
+    IRS_CHECK_ARG((size_t)T * sizeof(int) <= kCounterBytes, "T too large for the arrival counters (max 1024)");
     int rc = irs_load_params(model, params, n_params, &a.p);
     if (rc != IRS_OK) return rc;
     size_t need = irs_smooth_workspace_bytes(model, mode, T, N);
     if (workspace_bytes < need) {
-        irs_set_error("irs_smooth_accumulate: workspace %zu < %zu bytes", workspace_bytes, need);
+        irs_set_error("irs_smooth: workspace %zu < %zu bytes", workspace_bytes, need);
         return IRS_ERR_WORKSPACE;
     }
     a.x_trj = x_trj; a.u_trj = u_trj;
     a.T = T; a.N = N;
-    plan_grid(T, N, &a.chunk, &a.nblk);
-    a.partial = static_cast<float*>(workspace);
+    plan_grid(T, N, irs_reduce_pad(irs_sums_len(model, mode)) <= 64, rng, &a.chunk, &a.nblk, &a.block);
+    a.counters = static_cast<int*>(workspace);
+    a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + kCounterBytes);
+    a.sums = sums;
+    const bool fuse = out != nullptr;
+    if (fuse) {
+        IRS_CHECK_ARG(out->At && out->Bt && out->ct && out->info && out->n_total > 0, "null output pointer");
+        a.At = out->At; a.Bt = out->Bt; a.ct = out->ct; a.info = out->info;
+        a.n_total = (double)out->n_total;
+    }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int P = irs_sums_len(model, mode);
-    IRS_DISPATCH_MODEL(model, {
-        rc = rng ? launch_accum<Model, true>(mode, a, st) : launch_accum<Model, false>(mode, a, st);
-    });
+    IRS_DISPATCH_MODEL(model, { rc = launch_smooth<Model>(mode, a, rng, fuse, st); });
     if (rc != IRS_OK) return rc;
     IRS_CHECK_LAUNCH();
-    dim3 g2((P + 63) / 64, T);
-    hipLaunchKernelGGL(reduce_partials_kernel, g2, dim3(64), 0, st, a.partial, sums, a.nblk, P);
-    IRS_CHECK_LAUNCH();
+    return IRS_OK;
+}
+
+int fill_rng(int model, int mode, const double* std_x, const double* std_u, uint64_t seed, uint32_t iter,
+             uint64_t sample_offset, SmoothArgs& a) {
+    IRS_CHECK_ARG(std_u != nullptr, "std_u is null");
+    IRS_CHECK_ARG(std_x != nullptr || mode == IRS_SMOOTH_ZERO_ORDER_B, "std_x is null");
+    int n, m, np;
+    int rc = irs_model_info(model, &n, &m, &np);
+    if (rc != IRS_OK) return rc;
+    for (int i = 0; i < n; ++i) a.std[i] = std_x ? (float)std_x[i] : 0.f;
+    for (int j = 0; j < m; ++j) a.std[n + j] = (float)std_u[j];
+    a.seed = seed; a.iter = iter; a.sample_offset = sample_offset;
+    return IRS_OK;
+}
+
+int check_samples(const float* dx, const float* du, int mode) {
+    IRS_CHECK_ARG(du != nullptr, "du is null");
+    IRS_CHECK_ARG(dx != nullptr || mode == IRS_SMOOTH_ZERO_ORDER_B, "dx is null");
+    IRS_CHECK_ARG((reinterpret_cast<uintptr_t>(dx) & 15) == 0 && (reinterpret_cast<uintptr_t>(du) & 15) == 0,
+                  "dx/du must be 16-byte aligned");
     return IRS_OK;
 }
 
@@ -429,24 +703,29 @@ int irs_sums_len(int model, int mode) {
 size_t irs_smooth_workspace_bytes(int model, int mode, int T, int N) {
     int P = irs_sums_len(model, mode);
     if (P <= 0 || T <= 0 || N <= 0) return 0;
-    int chunk, nblk;
-    plan_grid(T, N, &chunk, &nblk);
-    return (size_t)T * nblk * P * sizeof(float);
+    int chunk, nblk, block;
+    plan_grid(T, N, irs_reduce_pad(P) <= 64, /*rng=*/true, &chunk, &nblk, &block);   // the larger grid
+    return kCounterBytes + (size_t)T * nblk * ((P + 3) / 4 * 4) * sizeof(float);
+}
+
+int irs_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
+    IRS_CHECK_ARG(workspace != nullptr && workspace_bytes >= (size_t)kCounterBytes, "workspace too small");
+    hipError_t e = hipMemsetAsync(workspace, 0, kCounterBytes, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) { irs_set_error("irs_workspace_init: %s", hipGetErrorString(e)); return IRS_ERR_HIP; }
+    return IRS_OK;
 }
 
 int irs_smooth_accumulate(int model, const double* params, int n_params, int mode, int T, int N,
                           const double* x_trj, const double* u_trj, const float* dx,
                           const float* du, double* sums, void* workspace,
                           size_t workspace_bytes, void* stream) {
-    IRS_CHECK_ARG(du != nullptr, "du is null");
-    IRS_CHECK_ARG(dx != nullptr || mode == IRS_SMOOTH_ZERO_ORDER_B, "dx is null");
-    IRS_CHECK_ARG((reinterpret_cast<uintptr_t>(dx) & 15) == 0 && (reinterpret_cast<uintptr_t>(du) & 15) == 0,
-                  "dx/du must be 16-byte aligned");
+    int rc = check_samples(dx, du, mode);
+    if (rc != IRS_OK) return rc;
     SmoothArgs a;
     memset(&a, 0, sizeof(a));
     a.dx = dx; a.du = du;
-    return accumulate_common(model, params, n_params, mode, T, N, x_trj, u_trj, a, false, sums,
-                             workspace, workspace_bytes, stream);
+    return smooth_common(model, params, n_params, mode, T, N, x_trj, u_trj, a, false, sums, nullptr,
+                         workspace, workspace_bytes, stream);
 }
 
 int irs_smooth_accumulate_rng(int model, const double* params, int n_params, int mode, int T, int N,
@@ -454,18 +733,57 @@ int irs_smooth_accumulate_rng(int model, const double* params, int n_params, int
                               const double* std_u, uint64_t seed, uint32_t iter,
                               uint64_t sample_offset, double* sums, void* workspace,
                               size_t workspace_bytes, void* stream) {
-    IRS_CHECK_ARG(std_u != nullptr, "std_u is null");
-    IRS_CHECK_ARG(std_x != nullptr || mode == IRS_SMOOTH_ZERO_ORDER_B, "std_x is null");
-    int n, m, np;
-    int rc = irs_model_info(model, &n, &m, &np);
+    SmoothArgs a;
+    memset(&a, 0, sizeof(a));
+    int rc = fill_rng(model, mode, std_x, std_u, seed, iter, sample_offset, a);
+    if (rc != IRS_OK) return rc;
+    return smooth_common(model, params, n_params, mode, T, N, x_trj, u_trj, a, true, sums, nullptr,
+                         workspace, workspace_bytes, stream);
+}
+
+int irs_smooth(int model, const double* params, int n_params, int mode, int T, int N,
+               const double* x_trj, const double* u_trj, const float* dx, const float* du,
+               double* sums, double* At, double* Bt, double* ct, int* info, void* workspace,
+               size_t workspace_bytes, void* stream) {
+    int rc = check_samples(dx, du, mode);
     if (rc != IRS_OK) return rc;
     SmoothArgs a;
     memset(&a, 0, sizeof(a));
-    for (int i = 0; i < n; ++i) a.std[i] = std_x ? (float)std_x[i] : 0.f;
-    for (int j = 0; j < m; ++j) a.std[n + j] = (float)std_u[j];
-    a.seed = seed; a.iter = iter; a.sample_offset = sample_offset;
-    return accumulate_common(model, params, n_params, mode, T, N, x_trj, u_trj, a, true, sums,
-                             workspace, workspace_bytes, stream);
+    a.dx = dx; a.du = du;
+    SmoothOut out{At, Bt, ct, info, (long long)N};
+    return smooth_common(model, params, n_params, mode, T, N, x_trj, u_trj, a, false, sums, &out,
+                         workspace, workspace_bytes, stream);
+}
+
+int irs_smooth_rng(int model, const double* params, int n_params, int mode, int T, int N,
+                   const double* x_trj, const double* u_trj, const double* std_x, const double* std_u,
+                   uint64_t seed, uint32_t iter, double* sums, double* At, double* Bt, double* ct,
+                   int* info, void* workspace, size_t workspace_bytes, void* stream) {
+    SmoothArgs a;
+    memset(&a, 0, sizeof(a));
+    int rc = fill_rng(model, mode, std_x, std_u, seed, iter, 0, a);
+    if (rc != IRS_OK) return rc;
+    SmoothOut out{At, Bt, ct, info, (long long)N};
+    return smooth_common(model, params, n_params, mode, T, N, x_trj, u_trj, a, true, sums, &out,
+                         workspace, workspace_bytes, stream);
+}
+
+int irs_smooth_run(const irs_smooth_call* c, void* stream) {
+    IRS_CHECK_ARG(c != nullptr, "null call struct");
+    SmoothArgs a;
+    memset(&a, 0, sizeof(a));
+    int rc;
+    if (c->use_rng) {
+        rc = fill_rng(c->model, c->mode, c->std_x, c->std_u, c->seed, c->iter, c->sample_offset, a);
+    } else {
+        rc = check_samples(c->dx, c->du, c->mode);
+        a.dx = c->dx; a.du = c->du;
+    }
+    if (rc != IRS_OK) return rc;
+    SmoothOut out{c->At, c->Bt, c->ct, c->info, c->n_total};
+    return smooth_common(c->model, c->params, c->n_params, c->mode, c->T, c->N, c->x_trj, c->u_trj, a,
+                         c->use_rng != 0, c->sums, c->At ? &out : nullptr, c->workspace,
+                         c->workspace_bytes, stream);
 }
 
 int irs_rng_samples(int n, int m, int T, int N, const double* std_x, const double* std_u,
@@ -493,10 +811,11 @@ int irs_smooth_finalize(int model, const double* params, int n_params, int mode,
     IRS_CHECK_ARG(T > 0 && N_total > 0, "T and N_total must be positive");
     IRS_CHECK_ARG(x_trj && u_trj && sums && At && Bt && ct && info, "null pointer");
     IRS_CHECK_ARG(mode >= 0 && mode <= 2, "unknown smoothing mode");
-    FinalizeArgs a;
+    SmoothArgs a;
+    memset(&a, 0, sizeof(a));
     int rc = irs_load_params(model, params, n_params, &a.p);
     if (rc != IRS_OK) return rc;
-    a.x_trj = x_trj; a.u_trj = u_trj; a.sums = sums;
+    a.x_trj = x_trj; a.u_trj = u_trj; a.sums = const_cast<double*>(sums);
     a.At = At; a.Bt = Bt; a.ct = ct; a.info = info;
     a.n_total = (double)N_total; a.T = T;
     hipStream_t st = static_cast<hipStream_t>(stream);

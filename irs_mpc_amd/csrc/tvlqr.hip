@@ -3,14 +3,24 @@
 //
 // Both are T-step sequential chains on matrices of order n <= 32: latency-bound, not
 // bandwidth- or FLOP-bound.  Each runs as ONE wave (64 lanes) with its state in LDS
-// (f64) -- no inter-workgroup synchronisation, no host round trips; lanes split the
-// output elements of every small product.
+// (f64): no workgroup barriers (a single wave's LDS traffic is ordered), no
+// inter-workgroup synchronisation, no host round trips.  Lanes split the output
+// elements of every small product; the next step's A,B,c (backward) or K,k (forward)
+// are prefetched into registers while the current step computes.
 #include "irs_common.hpp"
 
 namespace {
 
 constexpr int kMaxN = 32;
 constexpr int kMaxM = 16;
+
+// Orders ONE wave's LDS traffic: the LDS executes a wave's operations in issue order,
+// so this only has to stop the compiler from moving them; it deliberately does not
+// wait for outstanding global loads (the prefetches stay in flight).
+__device__ __forceinline__ void wave_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
 
 struct RiccatiArgs {
     const double* At; const double* Bt; const double* ct;
@@ -22,7 +32,395 @@ struct RiccatiArgs {
     int n, m, T;
 };
 
-// LDS matrices are stored with leading dimension n (or m) -- runtime sizes.
+// ------------------------------------------------------------------ compile-time sizes
+template <int N, int M>
+struct RiccatiLds {
+    double P[N * N], A[N * N], Acl[N * N], W[N * N], Q[N * N];
+    double B[N * M], PB[N * M], Kt[M * N], G1[M * N];
+    double H[M * M], R[M * M];
+    double p[N], c[N], qv[N], xd[N], g[M], kt[M];
+    int bad;
+};
+
+// Backward pass.  On return K (T,M,N) / k (T,M) are in global memory.
+template <int N, int M>
+__device__ __forceinline__ void riccati_backward(const RiccatiArgs& a, int lane, RiccatiLds<N, M>& S) {
+    constexpr int NN = N * N, NM = N * M;
+    constexpr int RA = (NN + 63) / 64, RB = (NM + 63) / 64;
+    const int T = a.T;
+
+    for (int q = lane; q < NN; q += 64) { S.P[q] = a.Qd[q]; S.Q[q] = a.Q[q]; }
+    for (int q = lane; q < M * M; q += 64) S.R[q] = a.alpha * a.R[q];
+    if (lane == 0) S.bad = 0;
+    // step T-1 operands
+    {
+        const double* At = a.At + (size_t)(T - 1) * NN;
+        const double* Bt = a.Bt + (size_t)(T - 1) * NM;
+        for (int q = lane; q < NN; q += 64) S.A[q] = At[q];
+        for (int q = lane; q < NM; q += 64) S.B[q] = Bt[q];
+        if (lane < N) {
+            S.c[lane] = a.ct[(size_t)(T - 1) * N + lane];
+            S.xd[lane] = a.xd[(size_t)(T - 1) * N + lane];
+        }
+    }
+    wave_sync();
+    if (lane < N) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) s -= S.P[lane * N + j] * a.xd[(size_t)T * N + j];
+        S.p[lane] = s;
+    }
+    wave_sync();
+
+    for (int t = T - 1; t >= 0; --t) {
+        // prefetch the operands of step t-1 (independent of this step's arithmetic)
+        double ra[RA], rb[RB], rc = 0.0, rxd = 0.0;
+        const int tp = t > 0 ? t - 1 : 0;
+#pragma unroll
+        for (int r = 0; r < RA; ++r) { int q = lane + 64 * r; ra[r] = q < NN ? a.At[(size_t)tp * NN + q] : 0.0; }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) { int q = lane + 64 * r; rb[r] = q < NM ? a.Bt[(size_t)tp * NM + q] : 0.0; }
+        if (lane < N) { rc = a.ct[(size_t)tp * N + lane]; rxd = a.xd[(size_t)tp * N + lane]; }
+
+        // 1. PB = P B ; qv = P c + p
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            int q = lane + 64 * r;
+            if (q < NM) {
+                int i = q / M, j = q % M;
+                double s = 0.0;
+#pragma unroll
+                for (int l = 0; l < N; ++l) s += S.P[i * N + l] * S.B[l * M + j];
+                S.PB[q] = s;
+            }
+        }
+        if (lane < N) {
+            double s = S.p[lane];
+#pragma unroll
+            for (int l = 0; l < N; ++l) s += S.P[lane * N + l] * S.c[l];
+            S.qv[lane] = s;
+        }
+        wave_sync();
+        // 2. H = alpha R + B'PB ; G1 = (PB)'A ; g = B'q
+        for (int q = lane; q < M * M; q += 64) {
+            int i = q / M, j = q % M;
+            double s = S.R[q];
+#pragma unroll
+            for (int l = 0; l < N; ++l) s += S.B[l * M + i] * S.PB[l * M + j];
+            S.H[q] = s;
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            int q = lane + 64 * r;
+            if (q < NM) {
+                int i = q / N, j = q % N;
+                double s = 0.0;
+#pragma unroll
+                for (int l = 0; l < N; ++l) s += S.PB[l * M + i] * S.A[l * N + j];
+                S.G1[q] = s;
+            }
+        }
+        if (lane < M) {
+            double s = 0.0;
+#pragma unroll
+            for (int l = 0; l < N; ++l) s += S.B[l * M + lane] * S.qv[l];
+            S.g[lane] = s;
+        }
+        wave_sync();
+        // 3. K = -H^-1 G1, k = -H^-1 g: every lane factors the M x M Hessian in registers
+        //    (LDL'), lanes 0..N-1 own a column of G1, lane N owns g.
+        {
+            double Lm[M][M], Dg[M], Dinv[M];
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                double dj = S.H[j * M + j];
+#pragma unroll
+                for (int l = 0; l < j; ++l) dj -= Lm[j][l] * Lm[j][l] * Dg[l];
+                ok = ok && (dj > 0.0);
+                Dg[j] = dj;
+                Dinv[j] = 1.0 / dj;
+#pragma unroll
+                for (int i = j + 1; i < M; ++i) {
+                    double s = S.H[i * M + j];
+#pragma unroll
+                    for (int l = 0; l < j; ++l) s -= Lm[i][l] * Lm[j][l] * Dg[l];
+                    Lm[i][j] = s * Dinv[j];
+                }
+            }
+            if (!ok && lane == 0 && S.bad == 0) S.bad = t + 1;
+            if (lane <= N) {
+                double y[M];
+#pragma unroll
+                for (int i = 0; i < M; ++i) {
+                    double s = (lane < N) ? S.G1[i * N + (lane < N ? lane : 0)] : S.g[i];
+#pragma unroll
+                    for (int l = 0; l < i; ++l) s -= Lm[i][l] * y[l];
+                    y[i] = s;
+                }
+#pragma unroll
+                for (int i = M - 1; i >= 0; --i) {
+                    double s = y[i] * Dinv[i];
+#pragma unroll
+                    for (int l = i + 1; l < M; ++l) s -= Lm[l][i] * y[l];
+                    y[i] = s;
+                }
+#pragma unroll
+                for (int i = 0; i < M; ++i) {
+                    if (lane < N) {
+                        S.Kt[i * N + lane] = -y[i];
+                        a.K[((size_t)t * M + i) * N + lane] = -y[i];
+                    } else {
+                        S.kt[i] = -y[i];
+                        a.k[(size_t)t * M + i] = -y[i];
+                    }
+                }
+            }
+        }
+        wave_sync();
+        // 4. Acl = A + B K
+#pragma unroll
+        for (int r = 0; r < RA; ++r) {
+            int q = lane + 64 * r;
+            if (q < NN) {
+                int i = q / N, j = q % N;
+                double s = S.A[q];
+#pragma unroll
+                for (int l = 0; l < M; ++l) s += S.B[i * M + l] * S.Kt[l * N + j];
+                S.Acl[q] = s;
+            }
+        }
+        wave_sync();
+        // 5. W = P Acl ; p_new = Acl' q - Q xd_t
+#pragma unroll
+        for (int r = 0; r < RA; ++r) {
+            int q = lane + 64 * r;
+            if (q < NN) {
+                int i = q / N, j = q % N;
+                double s = 0.0;
+#pragma unroll
+                for (int l = 0; l < N; ++l) s += S.P[i * N + l] * S.Acl[l * N + j];
+                S.W[q] = s;
+            }
+        }
+        double pnew = 0.0;
+        if (lane < N) {
+#pragma unroll
+            for (int l = 0; l < N; ++l) pnew += S.Acl[l * N + lane] * S.qv[l] - S.Q[lane * N + l] * S.xd[l];
+        }
+        wave_sync();
+        // 6. P = Q + sym(A'W); rotate in the prefetched operands of step t-1
+#pragma unroll
+        for (int r = 0; r < RA; ++r) {
+            int q = lane + 64 * r;
+            if (q < NN) {
+                int i = q / N, j = q % N;
+                double s = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int l = 0; l < N; ++l) {
+                    s += S.A[l * N + i] * S.W[l * N + j];
+                    s2 += S.A[l * N + j] * S.W[l * N + i];
+                }
+                S.P[q] = S.Q[q] + 0.5 * (s + s2);
+            }
+        }
+        if (lane < N) S.p[lane] = pnew;
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < RA; ++r) { int q = lane + 64 * r; if (q < NN) S.A[q] = ra[r]; }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) { int q = lane + 64 * r; if (q < NM) S.B[q] = rb[r]; }
+        if (lane < N) { S.c[lane] = rc; S.xd[lane] = rxd; }
+        wave_sync();
+    }
+    if (lane == 0) a.info[0] = S.bad;
+}
+
+// Tiny systems (N <= 4): the whole recursion lives in registers, every lane carrying
+// the same values (uniform addresses -> scalar loads); no LDS, no waits but the loads'.
+template <int N, int M>
+__device__ __forceinline__ void riccati_backward_reg(const RiccatiArgs& a, int lane) {
+    const int T = a.T;
+    double P[N][N], p[N], Q[N][N], R[M][M];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) { P[i][j] = a.Qd[i * N + j]; Q[i][j] = a.Q[i * N + j]; }
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) R[i][j] = a.alpha * a.R[i * M + j];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) s -= P[i][j] * a.xd[(size_t)T * N + j];
+        p[i] = s;
+    }
+    double An[N][N], Bn[N][M], cn[N], xdn[N];
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) An[i][j] = a.At[((size_t)t * N + i) * N + j];
+#pragma unroll
+            for (int j = 0; j < M; ++j) Bn[i][j] = a.Bt[((size_t)t * N + i) * M + j];
+            cn[i] = a.ct[(size_t)t * N + i];
+            xdn[i] = a.xd[(size_t)t * N + i];
+        }
+    };
+    fetch(T - 1);
+    int bad = 0;
+    for (int t = T - 1; t >= 0; --t) {
+        double A[N][N], B[N][M], c[N], xd[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) A[i][j] = An[i][j];
+#pragma unroll
+            for (int j = 0; j < M; ++j) B[i][j] = Bn[i][j];
+            c[i] = cn[i];
+            xd[i] = xdn[i];
+        }
+        fetch(t > 0 ? t - 1 : 0);
+        double PB[N][M], qv[N], H[M][M], G1[M][N], g[M];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                double s = 0.0;
+#pragma unroll
+                for (int l = 0; l < N; ++l) s += P[i][l] * B[l][j];
+                PB[i][j] = s;
+            }
+            double s = p[i];
+#pragma unroll
+            for (int l = 0; l < N; ++l) s += P[i][l] * c[l];
+            qv[i] = s;
+        }
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                double s = R[i][j];
+#pragma unroll
+                for (int l = 0; l < N; ++l) s += B[l][i] * PB[l][j];
+                H[i][j] = s;
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                double s = 0.0;
+#pragma unroll
+                for (int l = 0; l < N; ++l) s += PB[l][i] * A[l][j];
+                G1[i][j] = s;
+            }
+            double s = 0.0;
+#pragma unroll
+            for (int l = 0; l < N; ++l) s += B[l][i] * qv[l];
+            g[i] = s;
+        }
+        // LDL' of H, then K = -H^-1 G1, k = -H^-1 g
+        double Lm[M][M], Dg[M], Dinv[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            double dj = H[j][j];
+#pragma unroll
+            for (int l = 0; l < j; ++l) dj -= Lm[j][l] * Lm[j][l] * Dg[l];
+            if (!(dj > 0.0) && bad == 0) bad = t + 1;
+            Dg[j] = dj;
+            Dinv[j] = 1.0 / dj;
+#pragma unroll
+            for (int i = j + 1; i < M; ++i) {
+                double s = H[i][j];
+#pragma unroll
+                for (int l = 0; l < j; ++l) s -= Lm[i][l] * Lm[j][l] * Dg[l];
+                Lm[i][j] = s * Dinv[j];
+            }
+        }
+        double K[M][N], kk[M];
+#pragma unroll
+        for (int col = 0; col <= N; ++col) {
+            double y[M];
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                double s = col < N ? G1[i][col < N ? col : 0] : g[i];
+#pragma unroll
+                for (int l = 0; l < i; ++l) s -= Lm[i][l] * y[l];
+                y[i] = s;
+            }
+#pragma unroll
+            for (int i = M - 1; i >= 0; --i) {
+                double s = y[i] * Dinv[i];
+#pragma unroll
+                for (int l = i + 1; l < M; ++l) s -= Lm[l][i] * y[l];
+                y[i] = s;
+            }
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                if (col < N) K[i][col < N ? col : 0] = -y[i];
+                else kk[i] = -y[i];
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) a.K[((size_t)t * M + i) * N + j] = K[i][j];
+                a.k[(size_t)t * M + i] = kk[i];
+            }
+        }
+        double Acl[N][N], W[N][N], pn[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                double s = A[i][j];
+#pragma unroll
+                for (int l = 0; l < M; ++l) s += B[i][l] * K[l][j];
+                Acl[i][j] = s;
+            }
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                double s = 0.0;
+#pragma unroll
+                for (int l = 0; l < N; ++l) s += P[i][l] * Acl[l][j];
+                W[i][j] = s;
+            }
+            double s = 0.0;
+#pragma unroll
+            for (int l = 0; l < N; ++l) s += Acl[l][i] * qv[l] - Q[i][l] * xd[l];
+            pn[i] = s;
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                double s = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int l = 0; l < N; ++l) { s += A[l][i] * W[l][j]; s2 += A[l][j] * W[l][i]; }
+                P[i][j] = Q[i][j] + 0.5 * (s + s2);
+            }
+            p[i] = pn[i];
+        }
+    }
+    if (lane == 0) a.info[0] = bad;
+}
+
+template <int N, int M>
+__device__ __forceinline__ void riccati_backward_any(const RiccatiArgs& a, int lane, RiccatiLds<N, M>& S) {
+    if constexpr (N <= 4 && M <= 2) riccati_backward_reg<N, M>(a, lane);
+    else riccati_backward<N, M>(a, lane, S);
+}
+
+template <int N, int M>
+__global__ __launch_bounds__(64) void riccati_kernel_t(RiccatiArgs a) {
+    __shared__ RiccatiLds<N, M> S;
+    riccati_backward_any<N, M>(a, threadIdx.x, S);
+}
+
+// ------------------------------------------------------------------ generic runtime sizes
 __global__ __launch_bounds__(64) void riccati_kernel(RiccatiArgs a) {
     const int n = a.n, m = a.m, T = a.T, lane = threadIdx.x;
     __shared__ double P[kMaxN * kMaxN];     // value Hessian (n x n)
@@ -44,13 +442,13 @@ __global__ __launch_bounds__(64) void riccati_kernel(RiccatiArgs a) {
     for (int q = lane; q < n * n; q += 64) { P[q] = a.Qd[q]; Qs[q] = a.Q[q]; }
     for (int q = lane; q < m * m; q += 64) Rs[q] = a.R[q];
     if (lane == 0) bad = 0;
-    __syncthreads();
+    wave_sync();
     if (lane < n) {
         double s = 0.0;
         for (int j = 0; j < n; ++j) s -= P[lane * n + j] * a.xd[(size_t)T * n + j];
         pv[lane] = s;
     }
-    __syncthreads();
+    wave_sync();
 
     for (int t = T - 1; t >= 0; --t) {
         const double* At = a.At + (size_t)t * n * n;
@@ -58,8 +456,7 @@ __global__ __launch_bounds__(64) void riccati_kernel(RiccatiArgs a) {
         const double* ct = a.ct + (size_t)t * n;
         for (int q = lane; q < n * n; q += 64) A[q] = At[q];
         for (int q = lane; q < n * m; q += 64) B[q] = Bt[q];
-        __syncthreads();
-        // PB = P B ; q = P c + p
+        wave_sync();
         for (int q = lane; q < n * m; q += 64) {
             int i = q / m, j = q % m;
             double s = 0.0;
@@ -71,8 +468,7 @@ __global__ __launch_bounds__(64) void riccati_kernel(RiccatiArgs a) {
             for (int l = 0; l < n; ++l) s += P[lane * n + l] * ct[l];
             qv[lane] = s;
         }
-        __syncthreads();
-        // H = alpha R + B' PB ; G1 = PB' A (into Kt) ; g = B' q (into kt)
+        wave_sync();
         for (int q = lane; q < m * m; q += 64) {
             int i = q / m, j = q % m;
             double s = a.alpha * Rs[q];
@@ -90,8 +486,7 @@ __global__ __launch_bounds__(64) void riccati_kernel(RiccatiArgs a) {
             for (int l = 0; l < n; ++l) s += B[l * m + lane] * qv[l];
             kt[lane] = s;
         }
-        __syncthreads();
-        // Cholesky of H (m x m), lower in place
+        wave_sync();
         for (int j = 0; j < m; ++j) {
             double djj = Hm[j * ldh + j];
             if (!(djj > 0.0)) {
@@ -99,17 +494,16 @@ __global__ __launch_bounds__(64) void riccati_kernel(RiccatiArgs a) {
                 djj = 1.0;
             }
             double l = sqrt(djj);
-            __syncthreads();
+            wave_sync();
             if (lane == j) Hm[j * ldh + j] = l;
             if (lane > j && lane < m) Hm[lane * ldh + j] /= l;
-            __syncthreads();
+            wave_sync();
             for (int q = lane; q < m * m; q += 64) {
                 int r = q / m, c = q % m;
                 if (c > j && r >= c) Hm[r * ldh + c] -= Hm[r * ldh + j] * Hm[c * ldh + j];
             }
-            __syncthreads();
+            wave_sync();
         }
-        // K = -H^-1 G1 (one lane per column of G1), k = -H^-1 g (lane n)
         if (lane <= n) {
             double y[kMaxM];
             for (int i = 0; i < m; ++i) {
@@ -122,23 +516,22 @@ __global__ __launch_bounds__(64) void riccati_kernel(RiccatiArgs a) {
                 for (int l = i + 1; l < m; ++l) s -= Hm[l * ldh + i] * y[l];
                 y[i] = s / Hm[i * ldh + i];
             }
+            wave_sync();
             for (int i = 0; i < m; ++i) {
                 if (lane < n) Kt[i * n + lane] = -y[i];
                 else kt[i] = -y[i];
             }
         }
-        __syncthreads();
+        wave_sync();
         for (int q = lane; q < m * n; q += 64) a.K[(size_t)t * m * n + q] = Kt[q];
         if (lane < m) a.k[(size_t)t * m + lane] = kt[lane];
-        // Acl = A + B K
         for (int q = lane; q < n * n; q += 64) {
             int i = q / n, j = q % n;
             double s = A[q];
             for (int l = 0; l < m; ++l) s += B[i * m + l] * Kt[l * n + j];
             Acl[q] = s;
         }
-        __syncthreads();
-        // W = P Acl ; p_new = -Q xd_t + Acl' q
+        wave_sync();
         for (int q = lane; q < n * n; q += 64) {
             int i = q / n, j = q % n;
             double s = 0.0;
@@ -150,8 +543,7 @@ __global__ __launch_bounds__(64) void riccati_kernel(RiccatiArgs a) {
             const double* xd = a.xd + (size_t)t * n;
             for (int l = 0; l < n; ++l) pnew += Acl[l * n + lane] * qv[l] - Qs[lane * n + l] * xd[l];
         }
-        __syncthreads();
-        // P = Q + A' W, symmetrised
+        wave_sync();
         for (int q = lane; q < n * n; q += 64) {
             int i = q / n, j = q % n;
             double s = 0.0, s2 = 0.0;
@@ -162,7 +554,7 @@ __global__ __launch_bounds__(64) void riccati_kernel(RiccatiArgs a) {
             P[q] = Qs[q] + 0.5 * (s + s2);
         }
         if (lane < n) pv[lane] = pnew;
-        __syncthreads();
+        wave_sync();
     }
     if (lane == 0) a.info[0] = bad;
 }
@@ -175,7 +567,7 @@ __global__ __launch_bounds__(64) void linear_rollout_kernel(int n, int m, int T,
     __shared__ double u[kMaxM];
     const int lane = threadIdx.x;
     if (lane < n) { x[lane] = x0[lane]; xs[lane] = x0[lane]; }
-    __syncthreads();
+    wave_sync();
     for (int t = 0; t < T; ++t) {
         if (lane < m) {
             double s = k[(size_t)t * m + lane];
@@ -183,20 +575,20 @@ __global__ __launch_bounds__(64) void linear_rollout_kernel(int n, int m, int T,
             u[lane] = s;
             us[(size_t)t * m + lane] = s;
         }
-        __syncthreads();
+        wave_sync();
         double xn = 0.0;
         if (lane < n) {
             xn = ct[(size_t)t * n + lane];
             for (int j = 0; j < n; ++j) xn += At[((size_t)t * n + lane) * n + j] * x[j];
             for (int j = 0; j < m; ++j) xn += Bt[((size_t)t * n + lane) * m + j] * u[j];
         }
-        __syncthreads();
+        wave_sync();
         if (lane < n) { x[lane] = xn; xs[(size_t)(t + 1) * n + lane] = xn; }
-        __syncthreads();
+        wave_sync();
     }
 }
 
-// cost of one stage: (x-xd)'Q(x-xd) [+ u'Ru]
+// ------------------------------------------------------------------ rollouts on the true dynamics
 template <int n>
 __device__ __forceinline__ double quad_err(const double* Q, const double* x, const double* xd) {
     double e[n], s = 0.0;
@@ -212,22 +604,121 @@ __device__ __forceinline__ double quad_err(const double* Q, const double* x, con
     return s;
 }
 
-// Closed-loop (K != null) or open-loop (K == null, u = u_in) rollout on the TRUE
-// dynamics + evaluate_cost.  Sequential: every lane of the single wave carries the
-// same state in registers (no divergence, no broadcasts); lane 0 stores.
 template <class Model>
-__global__ __launch_bounds__(64) void rollout_kernel(ModelParams p, int T, const double* K,
-                                                     const double* k, const double* u_in,
-                                                     const double* x0, const double* Q,
-                                                     const double* R, const double* xd_trj,
-                                                     double* x_out, double* u_out, double* cost_out) {
-    constexpr int n = Model::NX, m = Model::NU;
-    __shared__ double Qs[n * n];
-    __shared__ double Rs[m * m];
-    const int lane = threadIdx.x;
-    for (int q = lane; q < n * n; q += 64) Qs[q] = Q[q];
-    for (int q = lane; q < m * m; q += 64) Rs[q] = R[q];
-    __syncthreads();
+struct RolloutLds {
+    double Q[Model::NX * Model::NX];
+    double R[Model::NU * Model::NU];
+    double K[Model::NU * Model::NX];
+    double k[Model::NU];
+    double xd[Model::NX];
+    double u[Model::NU];
+};
+
+// Closed-loop (K != null) or open-loop (K == null, u = u_in) rollout on the TRUE
+// dynamics + evaluate_cost.  Sequential in t: every lane of the single wave carries
+// the same state in registers (no divergence, no broadcasts); lane 0 stores.  The
+// next step's gains / references are prefetched into registers, staged through LDS.
+template <class Model>
+__device__ __forceinline__ void rollout_device(const ModelParams& p, int T, const double* K, const double* k,
+                                               const double* u_in, const double* x0, const double* Q,
+                                               const double* R, const double* xd_trj, double* x_out,
+                                               double* u_out, double* cost_out, int lane,
+                                               RolloutLds<Model>& S) {
+    constexpr int n = Model::NX, m = Model::NU, MN = m * n;
+    constexpr int RK = (MN + 63) / 64;
+    static_assert(m + n <= 64, "state too large for this staging scheme");
+    if constexpr (n <= 4 && m <= 2) {
+        // tiny model: everything in registers, uniform (scalar) loads one step ahead
+        double Qr[n][n], Rr[m][m], x[n], u[m], xn[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i)
+#pragma unroll
+            for (int j = 0; j < n; ++j) Qr[i][j] = Q[i * n + j];
+#pragma unroll
+        for (int i = 0; i < m; ++i)
+#pragma unroll
+            for (int j = 0; j < m; ++j) Rr[i][j] = R[i * m + j];
+#pragma unroll
+        for (int i = 0; i < n; ++i) x[i] = x0[i];
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < n; ++i) x_out[i] = x[i];
+        }
+        double Kn[m][n], kn[m], xdn[n];
+        auto fetch = [&](int t, bool gains) {
+            if (gains) {
+#pragma unroll
+                for (int i = 0; i < m; ++i) {
+                    if (K != nullptr) {
+#pragma unroll
+                        for (int j = 0; j < n; ++j) Kn[i][j] = K[((size_t)t * m + i) * n + j];
+                        kn[i] = k[(size_t)t * m + i];
+                    } else {
+                        kn[i] = u_in[(size_t)t * m + i];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < n; ++i) xdn[i] = xd_trj[(size_t)t * n + i];
+        };
+        fetch(0, true);
+        double cost = 0.0;
+        for (int t = 0; t < T; ++t) {
+            double e[n];
+#pragma unroll
+            for (int i = 0; i < m; ++i) {
+                double s = kn[i];
+                if (K != nullptr) {
+#pragma unroll
+                    for (int j = 0; j < n; ++j) s += Kn[i][j] * x[j];
+                }
+                u[i] = s;
+            }
+#pragma unroll
+            for (int i = 0; i < n; ++i) e[i] = x[i] - xdn[i];
+            fetch(t + 1, t + 1 < T);      // xd_trj has a row T; the gains do not
+#pragma unroll
+            for (int i = 0; i < n; ++i) {
+                double r = 0.0;
+#pragma unroll
+                for (int j = 0; j < n; ++j) r += Qr[i][j] * e[j];
+                cost += e[i] * r;
+            }
+#pragma unroll
+            for (int i = 0; i < m; ++i) {
+                double r = 0.0;
+#pragma unroll
+                for (int j = 0; j < m; ++j) r += Rr[i][j] * u[j];
+                cost += u[i] * r;
+            }
+            Model::template step<double>(p, x, u, xn);
+#pragma unroll
+            for (int i = 0; i < n; ++i) x[i] = xn[i];
+            if (lane == 0) {
+                if (u_out != nullptr) {
+#pragma unroll
+                    for (int i = 0; i < m; ++i) u_out[(size_t)t * m + i] = u[i];
+                }
+#pragma unroll
+                for (int i = 0; i < n; ++i) x_out[(size_t)(t + 1) * n + i] = x[i];
+            }
+        }
+        // terminal term uses Q, not Qd (irs_lqr/irs_lqr.py:135-136); xdn holds xd_T here
+        double eT[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i) eT[i] = x[i] - xdn[i];
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            double r = 0.0;
+#pragma unroll
+            for (int j = 0; j < n; ++j) r += Qr[i][j] * eT[j];
+            cost += eT[i] * r;
+        }
+        if (lane == 0) cost_out[0] = cost;
+        return;
+    }
+    for (int q = lane; q < n * n; q += 64) S.Q[q] = Q[q];
+    for (int q = lane; q < m * m; q += 64) S.R[q] = R[q];
     double x[n], u[m], xn[n];
 #pragma unroll
     for (int i = 0; i < n; ++i) x[i] = x0[i];
@@ -235,26 +726,48 @@ __global__ __launch_bounds__(64) void rollout_kernel(ModelParams p, int T, const
 #pragma unroll
         for (int i = 0; i < n; ++i) x_out[i] = x[i];
     }
+    // operands of step 0
+    double rk[RK], rv = 0.0;
+    auto fetch = [&](int t) {
+        if (K != nullptr) {
+#pragma unroll
+            for (int r = 0; r < RK; ++r) { int q = lane + 64 * r; rk[r] = q < MN ? K[(size_t)t * MN + q] : 0.0; }
+            if (lane < m) rv = k[(size_t)t * m + lane];
+        } else {
+            if (lane < m) rv = u_in[(size_t)t * m + lane];
+        }
+        if (lane >= m && lane < m + n) rv = xd_trj[(size_t)t * n + (lane - m)];
+    };
+    fetch(0);
     double cost = 0.0;
     for (int t = 0; t < T; ++t) {
+        wave_sync();
+        if (K != nullptr) {
+#pragma unroll
+            for (int r = 0; r < RK; ++r) { int q = lane + 64 * r; if (q < MN) S.K[q] = rk[r]; }
+        }
+        if (lane < m) S.k[lane] = rv;
+        if (lane >= m && lane < m + n) S.xd[lane - m] = rv;
+        wave_sync();
+        fetch(t + 1 < T ? t + 1 : t);
         if (K != nullptr) {
 #pragma unroll
             for (int i = 0; i < m; ++i) {
-                double s = k[(size_t)t * m + i];
+                double s = S.k[i];
 #pragma unroll
-                for (int j = 0; j < n; ++j) s += K[((size_t)t * m + i) * n + j] * x[j];
+                for (int j = 0; j < n; ++j) s += S.K[i * n + j] * x[j];
                 u[i] = s;
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < m; ++i) u[i] = u_in[(size_t)t * m + i];
+            for (int i = 0; i < m; ++i) u[i] = S.k[i];
         }
-        cost += quad_err<n>(Qs, x, xd_trj + (size_t)t * n);
+        cost += quad_err<n>(S.Q, x, S.xd);
 #pragma unroll
         for (int i = 0; i < m; ++i) {
             double r = 0.0;
 #pragma unroll
-            for (int j = 0; j < m; ++j) r += Rs[i * m + j] * u[j];
+            for (int j = 0; j < m; ++j) r += S.R[i * m + j] * u[j];
             cost += u[i] * r;
         }
         Model::template step<double>(p, x, u, xn);
@@ -270,8 +783,37 @@ __global__ __launch_bounds__(64) void rollout_kernel(ModelParams p, int T, const
         }
     }
     // terminal term uses Q, not Qd (irs_lqr/irs_lqr.py:135-136)
-    cost += quad_err<n>(Qs, x, xd_trj + (size_t)T * n);
+    double xdT[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) xdT[i] = xd_trj[(size_t)T * n + i];
+    cost += quad_err<n>(S.Q, x, xdT);
     if (lane == 0) cost_out[0] = cost;
+}
+
+template <class Model>
+__global__ __launch_bounds__(64) void rollout_kernel(ModelParams p, int T, const double* K,
+                                                     const double* k, const double* u_in,
+                                                     const double* x0, const double* Q,
+                                                     const double* R, const double* xd_trj,
+                                                     double* x_out, double* u_out, double* cost_out) {
+    __shared__ RolloutLds<Model> S;
+    rollout_device<Model>(p, T, K, k, u_in, x0, Q, R, xd_trj, x_out, u_out, cost_out, threadIdx.x, S);
+}
+
+// One launch for the whole of IrsLqr.local_descent after get_TV_matrices
+// (irs_lqr/irs_lqr.py:169-184) + evaluate_cost: backward Riccati, then the closed-loop
+// rollout of the policy it just wrote.
+template <class Model>
+__global__ __launch_bounds__(64) void descent_kernel(ModelParams p, RiccatiArgs a, const double* x0,
+                                                     double* x_new, double* u_new, double* cost_out) {
+    __shared__ RiccatiLds<Model::NX, Model::NU> S;
+    __shared__ RolloutLds<Model> S2;
+    const int lane = threadIdx.x;
+    riccati_backward_any<Model::NX, Model::NU>(a, lane, S);
+    // the gains were stored by this very wave: drain the stores, then re-read them
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    rollout_device<Model>(p, a.T, a.K, a.k, nullptr, x0, a.Q, a.R, a.xd, x_new, u_new, cost_out, lane, S2);
 }
 
 // evaluate_cost of a given trajectory pair: lanes stride over t, f64 wave reduction.
@@ -323,7 +865,10 @@ int irs_tvlqr_riccati(int n, int m, int T, const double* At, const double* Bt, c
     IRS_CHECK_ARG(n > 0 && n <= kMaxN && m > 0 && m <= kMaxM && T > 0, "need 0<n<=32, 0<m<=16, T>0");
     IRS_CHECK_ARG(At && Bt && ct && Q && Qd && R && xd_trj && K && k && info, "null pointer");
     RiccatiArgs a{At, Bt, ct, Q, Qd, R, xd_trj, K, k, info, alpha_R, n, m, T};
-    hipLaunchKernelGGL(riccati_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), a);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (n == 2 && m == 1) hipLaunchKernelGGL((riccati_kernel_t<2, 1>), dim3(1), dim3(64), 0, st, a);
+    else if (n == 12 && m == 4) hipLaunchKernelGGL((riccati_kernel_t<12, 4>), dim3(1), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(riccati_kernel, dim3(1), dim3(64), 0, st, a);
     IRS_CHECK_LAUNCH();
     return IRS_OK;
 }
@@ -368,6 +913,32 @@ int irs_rollout_cost(int model, const double* params, int n_params, int T, const
         hipLaunchKernelGGL((rollout_kernel<Model>), dim3(1), dim3(64), 0, st, p, T,
                            (const double*)nullptr, (const double*)nullptr, u_trj, x0, Q, R, xd_trj,
                            x_trj, (double*)nullptr, cost);
+    });
+    IRS_CHECK_LAUNCH();
+    return IRS_OK;
+}
+
+int irs_descent_run(const irs_descent_call* c, void* stream) {
+    IRS_CHECK_ARG(c != nullptr, "null call struct");
+    return irs_tvlqr_descent(c->model, c->params, c->n_params, c->T, c->At, c->Bt, c->ct, c->Q, c->Qd,
+                             c->R, c->alpha_R, c->xd_trj, c->x0, c->K, c->k, c->x_new, c->u_new, c->cost,
+                             c->info, stream);
+}
+
+int irs_tvlqr_descent(int model, const double* params, int n_params, int T, const double* At,
+                      const double* Bt, const double* ct, const double* Q, const double* Qd,
+                      const double* R, double alpha_R, const double* xd_trj, const double* x0,
+                      double* K, double* k, double* x_new, double* u_new, double* cost, int* info,
+                      void* stream) {
+    IRS_CHECK_ARG(T > 0 && At && Bt && ct && Q && Qd && R && xd_trj && x0 && K && k && x_new && u_new &&
+                  cost && info, "bad argument");
+    ModelParams p;
+    int rc = irs_load_params(model, params, n_params, &p);
+    if (rc != IRS_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    IRS_DISPATCH_MODEL(model, {
+        RiccatiArgs a{At, Bt, ct, Q, Qd, R, xd_trj, K, k, info, alpha_R, Model::NX, Model::NU, T};
+        hipLaunchKernelGGL((descent_kernel<Model>), dim3(1), dim3(64), 0, st, p, a, x0, x_new, u_new, cost);
     });
     IRS_CHECK_LAUNCH();
     return IRS_OK;

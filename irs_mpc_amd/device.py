@@ -4,6 +4,8 @@ the current HIP stream and (elsewhere) torch.distributed -- nothing else.
 Every function takes/returns torch tensors that live on the GPU; nothing here
 synchronises with the host.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -88,9 +90,67 @@ class DeviceModel:
         key = (mode, device)
         ws = self._ws.get(key)
         if ws is None or ws.numel() < need:
-            ws = torch.empty((max(need, 256),), dtype=torch.uint8, device=device)
+            ws = torch.empty((max(need, 8192),), dtype=torch.uint8, device=device)
+            check(self.lib.irs_workspace_init(ws.data_ptr(), ws.numel(), _stream()), "irs_workspace_init")
             self._ws[key] = ws
         return ws
+
+    def _tv_outputs(self, T, device, out):
+        if out is not None:
+            return out
+        return dict(sums=None,
+                    At=torch.empty((T, self.n, self.n), dtype=F64, device=device),
+                    Bt=torch.empty((T, self.n, self.m), dtype=F64, device=device),
+                    ct=torch.empty((T, self.n), dtype=F64, device=device),
+                    info=torch.empty((T,), dtype=torch.int32, device=device))
+
+    def smooth(self, mode, x_trj, u_trj, dx, du, out=None):
+        """Whole get_TV_matrices in one launch (single GPU), samples supplied.
+        Returns dict(sums, At, Bt, ct, info); pass `out` (a previous result) to reuse buffers."""
+        T, N = du.shape[0], du.shape[1]
+        o = self._tv_outputs(T, du.device, out)
+        if o["sums"] is None:
+            o["sums"] = torch.empty((T, self.sums_len(mode)), dtype=F64, device=du.device)
+        ws = self._workspace(mode, T, N, du.device)
+        check(self.lib.irs_smooth(self.model_id, self._p, self._np, mode, T, N, _ptr(x_trj, F64),
+                                  _ptr(u_trj, F64), _ptr(dx, F32), _ptr(du, F32), _ptr(o["sums"], F64),
+                                  _ptr(o["At"], F64), _ptr(o["Bt"], F64), _ptr(o["ct"], F64),
+                                  o["info"].data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "irs_smooth")
+        return o
+
+    def smooth_rng(self, mode, x_trj, u_trj, N, std_x, std_u, seed, it, out=None):
+        T = u_trj.shape[0]
+        o = self._tv_outputs(T, u_trj.device, out)
+        if o["sums"] is None:
+            o["sums"] = torch.empty((T, self.sums_len(mode)), dtype=F64, device=u_trj.device)
+        ws = self._workspace(mode, T, N, u_trj.device)
+        sx = dbl_array(std_x) if std_x is not None else None
+        check(self.lib.irs_smooth_rng(self.model_id, self._p, self._np, mode, T, N, _ptr(x_trj, F64),
+                                      _ptr(u_trj, F64), sx, dbl_array(std_u), int(seed), int(it),
+                                      _ptr(o["sums"], F64), _ptr(o["At"], F64), _ptr(o["Bt"], F64),
+                                      _ptr(o["ct"], F64), o["info"].data_ptr(), ws.data_ptr(), ws.numel(),
+                                      _stream()), "irs_smooth_rng")
+        return o
+
+    def tvlqr_descent(self, At, Bt, ct, Q, Qd, R, xd_trj, x0, alpha_R=0.5, out=None):
+        """Riccati backward pass + closed-loop rollout + cost in one launch."""
+        T = At.shape[0]
+        dev = At.device
+        o = out
+        if o is None:
+            o = dict(K=torch.empty((T, self.m, self.n), dtype=F64, device=dev),
+                     k=torch.empty((T, self.m), dtype=F64, device=dev),
+                     x_new=torch.empty((T + 1, self.n), dtype=F64, device=dev),
+                     u_new=torch.empty((T, self.m), dtype=F64, device=dev),
+                     cost=torch.empty((1,), dtype=F64, device=dev),
+                     info=torch.empty((1,), dtype=torch.int32, device=dev))
+        check(self.lib.irs_tvlqr_descent(self.model_id, self._p, self._np, T, _ptr(At, F64), _ptr(Bt, F64),
+                                         _ptr(ct, F64), _ptr(Q, F64), _ptr(Qd, F64), _ptr(R, F64),
+                                         float(alpha_R), _ptr(xd_trj, F64), _ptr(x0, F64), _ptr(o["K"], F64),
+                                         _ptr(o["k"], F64), _ptr(o["x_new"], F64), _ptr(o["u_new"], F64),
+                                         _ptr(o["cost"], F64), o["info"].data_ptr(), _stream()),
+              "irs_tvlqr_descent")
+        return o
 
     def smooth_accumulate(self, mode, x_trj, u_trj, dx, du, sums=None):
         """Sample pass on supplied samples: dx (T,N,n) f32 (None for ZERO_ORDER_B), du (T,N,m) f32."""
@@ -161,6 +221,111 @@ class DeviceModel:
                                                _ptr(x_new, F64), _ptr(u_new, F64), _ptr(cost, F64), _stream()),
               "irs_closed_loop_rollout")
         return x_new, u_new, cost
+
+
+class SmoothPlan:
+    """A pre-marshalled get_TV_matrices call (irs_smooth_call): `run()` is ONE FFI call
+    that enqueues ONE kernel (fused path) and touches no Python-side allocation.
+
+    Samples are either supplied (`dx`, `du` device f32 tensors) or drawn on the device
+    (`rng=dict(N=..., std_x=..., std_u=..., seed=..., iter=...)`).  With `fuse=False`
+    only `sums` is produced (multi-GPU path: all-reduce it, then `dm.smooth_finalize`)."""
+
+    def __init__(self, dm, mode, x_trj, u_trj, dx=None, du=None, rng=None, fuse=True, n_total=None,
+                 sample_offset=0):
+        self.dm, self.mode = dm, mode
+        T = u_trj.shape[0]
+        device = u_trj.device
+        c = _lib.SmoothCall()
+        c.model, c.n_params = dm.model_id, dm._np
+        for i, v in enumerate(dm.params):
+            c.params[i] = v
+        c.mode, c.T = mode, T
+        if rng is not None:
+            N = int(rng["N"])
+            c.use_rng = 1
+            c.seed, c.sample_offset = int(rng["seed"]), int(sample_offset)
+            self.set_iter(rng.get("iter", 1), rng.get("std_x"), rng["std_u"], call=c)
+        else:
+            N = du.shape[1]
+            c.use_rng = 0
+            c.dx, c.du = _ptr(dx, F32), _ptr(du, F32)
+        c.N = N
+        self.N = N
+        self.sums = torch.empty((T, dm.sums_len(mode)), dtype=F64, device=device)
+        c.sums = self.sums.data_ptr()
+        self.out = None
+        if fuse:
+            self.out = dm._tv_outputs(T, device, None)
+            self.out["sums"] = self.sums
+            c.At, c.Bt, c.ct = (self.out[k].data_ptr() for k in ("At", "Bt", "ct"))
+            c.info = self.out["info"].data_ptr()
+        c.n_total = int(n_total if n_total is not None else N)
+        self.ws = dm._workspace(mode, T, N, device)
+        c.workspace, c.workspace_bytes = self.ws.data_ptr(), self.ws.numel()
+        self.call = c
+        self._keep = (dx, du)
+        self.set_trajectory(x_trj, u_trj)
+        self._fn = dm.lib.irs_smooth_run
+        self._ref = ctypes.byref(c)
+
+    def set_trajectory(self, x_trj, u_trj):
+        self._xu = (x_trj, u_trj)
+        self.call.x_trj, self.call.u_trj = _ptr(x_trj, F64), _ptr(u_trj, F64)
+
+    def set_samples(self, dx, du):
+        self._keep = (dx, du)
+        self.call.dx, self.call.du = _ptr(dx, F32), _ptr(du, F32)
+
+    def set_iter(self, it, std_x, std_u, call=None):
+        c = call if call is not None else self.call
+        c.iter = int(it)
+        if std_x is not None:
+            for i, v in enumerate(std_x):
+                c.std_x[i] = float(v)
+        for i, v in enumerate(std_u):
+            c.std_u[i] = float(v)
+
+    def run(self, stream=None):
+        rc = self._fn(self._ref, _stream() if stream is None else stream)
+        if rc != 0:
+            check(rc, "irs_smooth_run")
+        return self.out if self.out is not None else self.sums
+
+
+class DescentPlan:
+    """A pre-marshalled irs_descent_call: Riccati + closed-loop rollout + cost, one launch."""
+
+    def __init__(self, dm, At, Bt, ct, Q, Qd, R, xd_trj, x0, alpha_R=0.5, x_new=None, u_new=None):
+        T = At.shape[0]
+        device = At.device
+        self.out = dict(K=torch.empty((T, dm.m, dm.n), dtype=F64, device=device),
+                        k=torch.empty((T, dm.m), dtype=F64, device=device),
+                        x_new=x_new if x_new is not None else torch.empty((T + 1, dm.n), dtype=F64, device=device),
+                        u_new=u_new if u_new is not None else torch.empty((T, dm.m), dtype=F64, device=device),
+                        cost=torch.empty((1,), dtype=F64, device=device),
+                        info=torch.empty((1,), dtype=torch.int32, device=device))
+        c = _lib.DescentCall()
+        c.model, c.n_params = dm.model_id, dm._np
+        for i, v in enumerate(dm.params):
+            c.params[i] = v
+        c.T, c.alpha_R = T, float(alpha_R)
+        self._keep = (At, Bt, ct, Q, Qd, R, xd_trj, x0)
+        c.At, c.Bt, c.ct = _ptr(At, F64), _ptr(Bt, F64), _ptr(ct, F64)
+        c.Q, c.Qd, c.R = _ptr(Q, F64), _ptr(Qd, F64), _ptr(R, F64)
+        c.xd_trj, c.x0 = _ptr(xd_trj, F64), _ptr(x0, F64)
+        for name in ("K", "k", "x_new", "u_new", "cost"):
+            setattr(c, name, self.out[name].data_ptr())
+        c.info = self.out["info"].data_ptr()
+        self.call = c
+        self._fn = dm.lib.irs_descent_run
+        self._ref = ctypes.byref(c)
+
+    def run(self, stream=None):
+        rc = self._fn(self._ref, _stream() if stream is None else stream)
+        if rc != 0:
+            check(rc, "irs_descent_run")
+        return self.out
 
 
 def evaluate_cost(x_trj, u_trj, Q, R, xd_trj):

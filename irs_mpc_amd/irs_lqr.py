@@ -135,11 +135,11 @@ class IrsLqr:
     def _local_descent_dev(self, x_trj, u_trj):
         At, Bt, ct = self._get_TV_matrices_dev(x_trj, u_trj)
         # T MPC re-solves of the tail QP == one Riccati pass + closed-loop rollout
-        # while the box bounds are inactive (checked below).
-        K, k, info = dev.tvlqr_riccati(At, Bt, ct, self._Q, self._Qd, self._R, self._xd, alpha_R=0.5)
-        x_new, u_new, cost = self._dm.closed_loop_rollout(K, k, x_trj[0].contiguous(), self._Q, self._R, self._xd)
-        self._last = dict(At=At, Bt=Bt, ct=ct, K=K, k=k, info=info)
-        return x_new, u_new, cost
+        # while the box bounds are inactive (checked in iterate()); one launch.
+        o = self._dm.tvlqr_descent(At, Bt, ct, self._Q, self._Qd, self._R, self._xd, x_trj[0].contiguous(),
+                                   alpha_R=0.5)
+        self._last = dict(At=At, Bt=Bt, ct=ct, K=o["K"], k=o["k"], info=o["info"])
+        return o["x_new"], o["u_new"], o["cost"]
 
     def _check_smooth_info(self):
         info = getattr(self, "_smooth_info", None)
@@ -165,6 +165,9 @@ class IrsLqr:
 
     # ---- irs_lqr/irs_lqr.py:188-218 ----------------------------------------
     def iterate(self, max_iterations):
+        """irs_lqr/irs_lqr.py:188-218: max_iterations+1 descents, the last one logged but
+        not adopted.  Per iteration: 2 kernel launches (3 with host-drawn samples' upload)
+        and one read-back of (x_new, u_new, cost) for the history lists."""
         x_dev = dev.to_dev(np.asarray(self.x_trj, float))
         u_dev = dev.to_dev(np.asarray(self.u_trj, float))
         while True:
@@ -219,7 +222,19 @@ class _IrsLqrSampled(IrsLqr):
 
     def _get_TV_matrices_dev(self, x_trj, u_trj):
         rank, world = dist_util.rank_world()
-        if isinstance(self.sampling, GaussianSmoothing) and getattr(self.sampling, "on_device", True):
+        on_device = isinstance(self.sampling, GaussianSmoothing) and getattr(self.sampling, "on_device", True)
+        if world == 1:
+            # single GPU: sample pass + reduction + solve in ONE launch
+            if on_device:
+                sx, su = self.sampling.stds(self.iter)
+                o = self._dm.smooth_rng(self.MODE, x_trj, u_trj, self.sampling.num_samples, sx, su,
+                                        self.sampling.seed, self.iter)
+            else:
+                dx, du = self._draw_host(x_trj, u_trj)
+                o = self._dm.smooth(self.MODE, x_trj, u_trj, dev.to_dev(dx, dev.F32), dev.to_dev(du, dev.F32))
+            self._smooth_info = o["info"]
+            return o["At"], o["Bt"], o["ct"]
+        if on_device:
             N = self.sampling.num_samples
             lo, hi = dist_util.shard_range(N, rank, world)
             sx, su = self.sampling.stds(self.iter)

@@ -267,6 +267,61 @@ def test_shard_sum_invariance_full_size(amd):
     assert torch.equal(again, full)
 
 
+@pytest.mark.parametrize("name,mode_name", [("pendulum", "ZERO_ORDER_AB"), ("quadrotor", "ZERO_ORDER_AB"),
+                                            ("quadrotor", "FIRST_ORDER")])
+def test_fused_launch_equals_two_stage(amd, name, mode_name):
+    """irs_smooth (one launch) == irs_smooth_accumulate + irs_smooth_finalize (the
+    multi-GPU path), bit for bit, including repeated use of one workspace and a
+    change of N in between (arrival counters re-arm)."""
+    from irs_mpc_amd import _lib, device as dev
+    mode = getattr(_lib, "SMOOTH_" + mode_name)
+    sys_d, sys_o = systems(amd, name)
+    n, m = sys_o.dim_x, sys_o.dim_u
+    T = 9
+    params = (pend_params if name == "pendulum" else quad_params)(amd, T)
+    x_trj = dev.to_dev(orc.rollout(sys_o, params.x0, params.u_trj_initial))
+    u_trj = dev.to_dev(params.u_trj_initial)
+    dm = sys_d.dm()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for N in (5000, 700, 5000, 123457):
+        dx = 0.1 * torch.randn((T, N, n), generator=g, device="cuda", dtype=torch.float32)
+        du = 0.1 * torch.randn((T, N, m), generator=g, device="cuda", dtype=torch.float32)
+        o = dm.smooth(mode, x_trj, u_trj, dx, du)
+        sums = dm.smooth_accumulate(mode, x_trj, u_trj, dx, du)
+        At, Bt, ct, info = dm.smooth_finalize(mode, N, x_trj, u_trj, sums)
+        # two instantiations of one template: the compiler may contract FMAs differently,
+        # so the f32 sums agree to rounding rather than bit for bit
+        scale = sums.abs().max().item()
+        np.testing.assert_allclose(o["sums"].cpu().numpy(), sums.cpu().numpy(), rtol=1e-5, atol=1e-6 * scale)
+        np.testing.assert_allclose(o["At"].cpu().numpy(), At.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(o["Bt"].cpu().numpy(), Bt.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(o["ct"].cpu().numpy(), ct.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        assert int(info.abs().sum().item()) == 0 and int(o["info"].abs().sum().item()) == 0
+        # the same launch twice IS bit-identical (fixed-order reductions, no float atomics)
+        o2 = dm.smooth(mode, x_trj, u_trj, dx, du)
+        assert torch.equal(o2["sums"], o["sums"]) and torch.equal(o2["At"], o["At"])
+
+
+def test_riccati_generic_sizes_vs_oracle(amd):
+    """irs_tvlqr_riccati for (n,m) without a compile-time specialisation."""
+    from irs_mpc_amd import device as dev
+    rng = np.random.default_rng(4)
+    for n, m, T in ((3, 2, 17), (7, 4, 40), (32, 16, 5), (1, 1, 3)):
+        At = np.eye(n) + 0.1 * rng.normal(size=(T, n, n))
+        Bt = rng.normal(size=(T, n, m))
+        ct = 0.1 * rng.normal(size=(T, n))
+        Q, Qd, R = np.eye(n) * 2.0, np.eye(n) * 5.0, np.eye(m) * 0.7
+        xd = rng.normal(size=(T + 1, n))
+        K, k, info = dev.tvlqr_riccati(*[dev.to_dev(a) for a in (At, Bt, ct, Q, Qd, R, xd)], alpha_R=0.5)
+        Ko, ko = orc.tvlqr_riccati(At, Bt, ct, Q, Qd, R, xd, alpha_R=0.5)
+        assert int(info.item()) == 0
+        np.testing.assert_allclose(K.cpu().numpy(), Ko, rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(k.cpu().numpy(), ko, rtol=1e-8, atol=1e-9)
+    # an indefinite Hessian is reported, LAPACK style
+    K, k, info = dev.tvlqr_riccati(*[dev.to_dev(a) for a in (At, Bt, ct, -Q * 50, -Qd * 50, R, xd)], alpha_R=0.5)
+    assert int(info.item()) != 0
+
+
 # ---------------------------------------------------------------- device RNG (mode G)
 def test_device_rng_matches_specification(amd):
     dm = amd.QuadrotorDynamics(0.05).dm()
