@@ -5,7 +5,7 @@ iterations / s (that + Riccati + closed-loop rollout + cost), BASELINE.json conf
 pendulum zero-order, T=30, N=10000 samples per timestep PER GPU, samples resident in
 HBM (f32).  One process per GPU; N>1 is launched by torch.distributed.run.
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 1 --steps 20000 --warmup 2000
 
 A "step" = one smoothing pass over the (T x N) sample grid = ONE kernel launch on one
 GPU.  With --gpus N every rank holds its own N samples per timestep (weak scaling) and
@@ -56,8 +56,8 @@ def cpu_baseline(T, N, seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--T", type=int, default=30)
     ap.add_argument("--N", type=int, default=10000, help="samples per timestep per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -93,22 +93,32 @@ def main():
             dist.barrier()
 
     def timed(fn, steps, warmup):
+        """W untimed steps, then EXACTLY `steps` steps between barrier+synchronize pairs
+        (host clock, max over ranks).  Also returns the same region measured by a HIP
+        event pair recorded on the launch stream (device clock)."""
+        t_end = time.perf_counter() + 0.25        # bring the clocks up before the W warmup steps
+        while time.perf_counter() < t_end:
+            fn()
         for _ in range(warmup):
             fn()
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        ev0.record()
         for _ in range(steps):
             fn()
+        ev1.record()
         torch.cuda.synchronize()
         barrier()
         el = time.perf_counter() - t0
+        ev_ms = ev0.elapsed_time(ev1)
         if world > 1:
             t = torch.tensor([el], device="cuda", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        return el
+        return el, ev_ms
 
     def run(N, steps, warmup):
         g = torch.Generator(device="cuda").manual_seed(1234 + rank)
@@ -140,30 +150,27 @@ def main():
                 c.At, c.Bt, c.ct = tv["At"].data_ptr(), tv["Bt"].data_ptr(), tv["ct"].data_ptr()
             descent.run(stream)
 
-        el = timed(smooth_step, steps, warmup)
-        el_it = timed(ilqr_step, steps, warmup)
-        # Duration of the sample-pass kernel: HIP events recorded on the stream the kernel
-        # is launched on (torch's current stream is the one handed to the C ABI).
-        reps = min(steps, 200)
-
-        def event_pairs(body):
-            starts = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
-            ends = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
-            for i in range(reps):
-                starts[i].record()
-                body()
-                ends[i].record()
+        el, ev_ms = timed(smooth_step, steps, warmup)
+        el_it, _ = timed(ilqr_step, steps, warmup)
+        # Kernel time of the sample pass: HIP events recorded on the stream the kernel is
+        # launched on (torch's current stream is the one handed to the C ABI), bracketing
+        # `steps` launches of the timed region when the step is a single launch, otherwise
+        # a dedicated loop of sample-pass launches.  Per-launch average = elapsed / launches
+        # (back-to-back launches: includes the ~1 us dispatch gap, no per-event overhead).
+        if world == 1:
+            k_ms = ev_ms / steps
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                plan.run(stream)
+            e1.record()
             torch.cuda.synchronize()
-            return sorted(s.elapsed_time(e) for s, e in zip(starts, ends))
-
-        ts = event_pairs(lambda: plan.run(stream))
-        empty = event_pairs(lambda: None)          # what an event pair costs with nothing between
-        ovh = float(np.median(empty))
-        return el, el_it, float(np.mean(ts)), float(ts[len(ts) // 2]), ovh
+            k_ms = e0.elapsed_time(e1) / steps
+        return el, el_it, k_ms
 
     N = args.N
-    el, el_it, k_raw, k_med, ovh = run(N, args.steps, args.warmup)
-    k_mean = max(k_raw - ovh, 1e-6)                # launch duration net of the event pair's own cost
+    el, el_it, k_mean = run(N, args.steps, args.warmup)
     bytes_per_sample_step = 4 * (n + m)            # dx,du read once, f32
     alg_bytes = bytes_per_sample_step * N * T      # per launch (per GPU)
     achieved = alg_bytes / (k_mean * 1e-3) / 1e9
@@ -197,15 +204,15 @@ def main():
                      "kernel": "smooth_kernel<PendulumModel, ZERO_ORDER_AB> (sample pass + reduction + solve, "
                                "one launch)",
                      "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k_mean,
-                     "avg_event_pair_ms": k_raw, "empty_event_pair_ms": ovh, "median_event_pair_ms": k_med},
+                     "timing": "HIP event pair on the launch stream around the timed launches / launches"},
     }
     if args.sweep and world == 1:
         sweep = {}
         for Ns in (1000, 100000, 1000000):
-            st = max(20, args.steps // 4)
-            e, ei, km, kmed, ov = run(Ns, st, 5)
+            st = max(20, args.steps // (4 if Ns <= 100000 else 16))
+            e, ei, km = run(Ns, st, 5)
             sweep[str(Ns)] = {"value": Ns * T * st / e, "ilqr_iters_per_s": st / ei,
-                              "kernel_GBps": bytes_per_sample_step * Ns * T / (max(km - ov, 1e-6) * 1e-3) / 1e9}
+                              "kernel_GBps": bytes_per_sample_step * Ns * T / (km * 1e-3) / 1e9}
         out["sweep_N"] = sweep
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
