@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--T", type=int, default=30)
     ap.add_argument("--N", type=int, default=10000, help="samples per timestep per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="run all ranks on GPU 0 with gloo (exercises the N>1 code path on a 1-GPU box)")
     ap.add_argument("--sweep", action="store_true", help="also time N=1e3,1e5,1e6 (extra keys)")
     args = ap.parse_args()
 
@@ -68,10 +71,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if args.rehearse_one_gpu:       # testing aid: every rank on GPU 0, gloo collectives
+        local, args.backend = 0, "gloo"
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
 
     from irs_mpc_amd import PendulumDynamics, device as dev
     from irs_mpc_amd._lib import SMOOTH_ZERO_ORDER_AB as MODE
@@ -115,7 +123,7 @@ def main():
         el = time.perf_counter() - t0
         ev_ms = ev0.elapsed_time(ev1)
         if world > 1:
-            t = torch.tensor([el], device="cuda", dtype=torch.float64)
+            t = torch.tensor([el], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el, ev_ms

@@ -205,6 +205,22 @@ int irs_tvlqr_descent(int model, const double *params, int n_params, int T,
                       const double *xd_trj, const double *x0, double *K, double *k,
                       double *x_new, double *u_new, double *cost, int *info, void *stream);
 
+/* ---- Cross-entropy-method baseline (irs_lqr/cem.py:151-184) -------------------- */
+
+/* Steps 1-2 of CrossEntropyMethod.local_descent (cem.py:163-168): roll out each of the
+ * B candidate control sequences u_cand (B,T,m) DEV f64 from x0 on the true dynamics and
+ * evaluate its cost (evaluate_cost, cem.py:121-140) -> costs (B) DEV f64.             */
+int irs_cem_rollout_costs(int model, const double *params, int n_params, int T, int B,
+                          const double *u_cand, const double *x0, const double *Q,
+                          const double *R, const double *xd_trj, double *costs, void *stream);
+
+/* Steps 3-4 (cem.py:173-180): the n_elite cheapest candidates (np.argpartition) ->
+ * elite_idx (n_elite) DEV int32 (cheaper-than-threshold candidates in increasing index
+ * order, then threshold ties, lowest index first: deterministic), their mean -> u_new (T,m) and
+ * population standard deviation -> std_new (T,m), DEV f64.  Any m, T.               */
+int irs_cem_refit(int T, int m, int B, int n_elite, const double *u_cand, const double *costs,
+                  int *elite_idx, double *u_new, double *std_new, void *stream);
+
 /* ---- Pre-marshalled calls ------------------------------------------------------
  * The same operations with their arguments packed in a caller-owned struct, so that a
  * host loop (IrsLqr.iterate, irs_lqr/irs_lqr.py:188-218) pays one pointer-sized FFI

@@ -79,6 +79,9 @@ class DescentCall(ctypes.Structure):
                 ("cost", c_void_p), ("info", c_void_p)]
 
 
+SIGNATURES["irs_cem_rollout_costs"] = (c_int, [c_int, POINTER(c_double), c_int, c_int, c_int, _dp, _dp, _dp, _dp,
+                                               _dp, _dp, c_void_p])
+SIGNATURES["irs_cem_refit"] = (c_int, [c_int, c_int, c_int, c_int, _dp, _dp, _dp, _dp, _dp, c_void_p])
 SIGNATURES["irs_smooth_run"] = (c_int, [POINTER(SmoothCall), c_void_p])
 SIGNATURES["irs_descent_run"] = (c_int, [POINTER(DescentCall), c_void_p])
 

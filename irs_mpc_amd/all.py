@@ -4,3 +4,4 @@ from .irs_lqr import *            # noqa: F401,F403
 from .tv_lqr import *             # noqa: F401,F403
 from .systems import *            # noqa: F401,F403
 from .sampling import *           # noqa: F401,F403
+from .cem import *                # noqa: F401,F403

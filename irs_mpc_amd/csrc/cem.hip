@@ -1,0 +1,204 @@
+// Cross-entropy-method baseline: CrossEntropyMethod.local_descent (irs_lqr/cem.py:151-184).
+//   1. roll out every candidate control sequence u_cand[b] (B of them) for T steps on the
+//      true dynamics and evaluate its cost            (cem.py:163-168; the ONLY place the
+//      reference batches multi-step rollouts)         -> cem_rollout_kernel, one lane per b
+//   2. keep the n_elite cheapest (np.argpartition, :173) -> cem_select_kernel: radix select
+//      on order-preserving 64-bit keys + ordered compaction (deterministic)
+//   3. refit mean / std over the elites (:178-180)      -> cem_refit_kernel
+//   4. roll out the mean (:182)                          -> rollout_kernel (tvlqr.hip)
+// All arithmetic in f64: rollout costs only rank the candidates, but ties broken by f32
+// noise would change the elite set and hence the refit.
+#include "irs_common.hpp"
+
+namespace {
+
+template <class Model>
+__global__ __launch_bounds__(256) void cem_rollout_kernel(ModelParams p, int T, int B,
+                                                          const double* __restrict__ u_cand,
+                                                          const double* __restrict__ x0,
+                                                          const double* __restrict__ Q,
+                                                          const double* __restrict__ R,
+                                                          const double* __restrict__ xd_trj,
+                                                          double* __restrict__ costs) {
+    constexpr int n = Model::NX, m = Model::NU;
+    __shared__ double Qs[n * n];
+    __shared__ double Rs[m * m];
+    for (int q = threadIdx.x; q < n * n; q += blockDim.x) Qs[q] = Q[q];
+    for (int q = threadIdx.x; q < m * m; q += blockDim.x) Rs[q] = R[q];
+    __syncthreads();
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double x[n], u[m], xn[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) x[i] = x0[i];
+    const double* ub = u_cand + (size_t)b * T * m;
+    double cost = 0.0;
+    for (int t = 0; t <= T; ++t) {
+        // (x_t - xd_t)' Q (x_t - xd_t); the terminal term also uses Q (cem.py:138-139)
+        const double* xd = xd_trj + (size_t)t * n;      // uniform address: scalar loads
+        double e[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i) e[i] = x[i] - xd[i];
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            double r = 0.0;
+#pragma unroll
+            for (int j = 0; j < n; ++j) r += Qs[i * n + j] * e[j];
+            cost += e[i] * r;
+        }
+        if (t == T) break;
+#pragma unroll
+        for (int j = 0; j < m; ++j) u[j] = ub[(size_t)t * m + j];
+#pragma unroll
+        for (int i = 0; i < m; ++i) {
+            double r = 0.0;
+#pragma unroll
+            for (int j = 0; j < m; ++j) r += Rs[i * m + j] * u[j];
+            cost += u[i] * r;
+        }
+        Model::template step<double>(p, x, u, xn);
+#pragma unroll
+        for (int i = 0; i < n; ++i) x[i] = xn[i];
+    }
+    costs[b] = cost;
+}
+
+// Order-preserving map f64 -> u64 (NaN sorts last: a diverged rollout is never elite).
+__device__ __forceinline__ unsigned long long cost_key(double c) {
+    if (c != c) return ~0ull;
+    unsigned long long b = (unsigned long long)__double_as_longlong(c);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+constexpr int kSelBlock = 1024;
+
+// Single workgroup.  Finds the n_elite smallest costs; writes their indices in increasing
+// index order (ties at the threshold: lowest indices first) -> elite_idx[0..n_elite).
+__global__ __launch_bounds__(kSelBlock) void cem_select_kernel(const double* __restrict__ costs, int B,
+                                                               int n_elite, int* __restrict__ elite_idx) {
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned long long s_prefix;
+    __shared__ int s_k;
+    __shared__ int scan[kSelBlock];
+    __shared__ int s_less_total;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_prefix = 0ull; s_k = n_elite; }
+    __syncthreads();
+    // MSB-first radix select of the n_elite-th smallest key
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 56 - 8 * pass;
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        const unsigned long long prefix = s_prefix;
+        const unsigned long long mask = pass == 0 ? 0ull : (~0ull << (shift + 8));
+        for (int i = tid; i < B; i += kSelBlock) {
+            unsigned long long key = cost_key(costs[i]);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 0xFF], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int k = s_k, bin = 0;
+            for (; bin < 256; ++bin) {
+                int c = (int)hist[bin];
+                if (k <= c) break;
+                k -= c;
+            }
+            s_k = k;                                   // rank inside the chosen bin
+            s_prefix = prefix | ((unsigned long long)bin << shift);
+        }
+        __syncthreads();
+    }
+    const unsigned long long thr = s_prefix;           // key of the n_elite-th smallest cost
+    const int need_equal = s_k;                        // how many keys == thr belong to the elite
+    // ordered compaction: thread owns a contiguous chunk of indices
+    const int chunk = (B + kSelBlock - 1) / kSelBlock;
+    const int lo = tid * chunk, hi = min(B, lo + chunk);
+    int n_less = 0, n_eq = 0;
+    for (int i = lo; i < hi; ++i) {
+        unsigned long long key = cost_key(costs[i]);
+        n_less += key < thr;
+        n_eq += key == thr;
+    }
+    // exclusive scans of n_less and n_eq over the threads (two passes through one buffer)
+    auto block_exclusive_scan = [&](int v, int* total) {
+        scan[tid] = v;
+        __syncthreads();
+        for (int off = 1; off < kSelBlock; off <<= 1) {
+            int add = tid >= off ? scan[tid - off] : 0;
+            __syncthreads();
+            scan[tid] += add;
+            __syncthreads();
+        }
+        int incl = scan[tid];
+        if (total != nullptr && tid == kSelBlock - 1) *total = incl;
+        __syncthreads();
+        return incl - v;
+    };
+    const int less_before = block_exclusive_scan(n_less, &s_less_total);
+    const int eq_before = block_exclusive_scan(n_eq, nullptr);
+    const int less_total = s_less_total;               // == n_elite - need_equal
+    int wl = less_before, we = eq_before;
+    for (int i = lo; i < hi; ++i) {
+        unsigned long long key = cost_key(costs[i]);
+        if (key < thr) {
+            elite_idx[wl++] = i;                        // provisional slot; merged below
+        } else if (key == thr) {
+            if (we < need_equal) elite_idx[less_total + we] = i;
+            ++we;
+        }
+    }
+}
+
+// u_new = mean over elites, std_new = population std over elites (np.mean / np.std, axis 0).
+__global__ void cem_refit_kernel(const double* __restrict__ u_cand, const int* __restrict__ elite_idx,
+                                 int n_elite, int Tm, double* __restrict__ u_new,
+                                 double* __restrict__ std_new) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Tm) return;
+    double s = 0.0;
+    for (int e = 0; e < n_elite; ++e) s += u_cand[(size_t)elite_idx[e] * Tm + q];
+    const double mean = s / n_elite;
+    double v = 0.0;
+    for (int e = 0; e < n_elite; ++e) {
+        double d = u_cand[(size_t)elite_idx[e] * Tm + q] - mean;
+        v += d * d;
+    }
+    u_new[q] = mean;
+    std_new[q] = sqrt(v / n_elite);
+}
+
+}  // namespace
+
+extern "C" {
+
+int irs_cem_rollout_costs(int model, const double* params, int n_params, int T, int B,
+                          const double* u_cand, const double* x0, const double* Q, const double* R,
+                          const double* xd_trj, double* costs, void* stream) {
+    IRS_CHECK_ARG(T > 0 && B > 0 && u_cand && x0 && Q && R && xd_trj && costs, "bad argument");
+    ModelParams p;
+    int rc = irs_load_params(model, params, n_params, &p);
+    if (rc != IRS_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    IRS_DISPATCH_MODEL(model, {
+        hipLaunchKernelGGL((cem_rollout_kernel<Model>), dim3((B + 255) / 256), dim3(256), 0, st, p, T, B,
+                           u_cand, x0, Q, R, xd_trj, costs);
+    });
+    IRS_CHECK_LAUNCH();
+    return IRS_OK;
+}
+
+int irs_cem_refit(int T, int m, int B, int n_elite, const double* u_cand, const double* costs,
+                  int* elite_idx, double* u_new, double* std_new, void* stream) {
+    IRS_CHECK_ARG(T > 0 && m > 0 && B > 0 && n_elite > 0 && n_elite <= B, "need 0 < n_elite <= B");
+    IRS_CHECK_ARG(u_cand && costs && elite_idx && u_new && std_new, "null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(cem_select_kernel, dim3(1), dim3(kSelBlock), 0, st, costs, B, n_elite, elite_idx);
+    IRS_CHECK_LAUNCH();
+    const int Tm = T * m;
+    hipLaunchKernelGGL(cem_refit_kernel, dim3((Tm + 63) / 64), dim3(64), 0, st, u_cand, elite_idx, n_elite, Tm,
+                       u_new, std_new);
+    IRS_CHECK_LAUNCH();
+    return IRS_OK;
+}
+
+}  // extern "C"

@@ -45,11 +45,38 @@ IRS_HD void irs_sincos_quadrant(float r, int qi, float& s, float& c) {
     s = (qi & 2) ? -ss : ss;
     c = ((qi + 1) & 2) ? -cc : cc;
 }
-IRS_HD void irs_sincos(double x, double& s, double& c) { s = sin(x); c = cos(x); }
+// f64 pair for the sequential chains (rollouts, nominal point): the same quadrant
+// reduction with a hi/lo split of pi/2 and the fdlibm kernel polynomials (k_sin.c /
+// k_cos.c coefficients, < 1 ulp on [-pi/4, pi/4]).  ~35 dependent f64 operations instead
+// of two ocml calls with large-argument paths: the rollout chain is latency-bound on this.
+// Accurate to ~1 ulp for |x| < 1e6.
+IRS_HD void irs_sincos(double x, double& s, double& c) {
+    const double q = rint(x * 0.63661977236758134308);
+    double r = fma(q, -1.57079632679489655800, x);              // pi/2 hi
+    r = fma(q, -6.12323399573676603587e-17, r);                 // pi/2 lo
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(ps, z, 2.75573137070700676789e-06);
+    ps = fma(ps, z, -1.98412698298579493134e-04);
+    ps = fma(ps, z, 8.33333333332248946124e-03);
+    ps = fma(ps, z, -1.66666666666666324348e-01);
+    ps = fma(ps * z, r, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(pc, z, -2.75573143513906633035e-07);
+    pc = fma(pc, z, 2.48015872894767294178e-05);
+    pc = fma(pc, z, -1.38888888888741095749e-03);
+    pc = fma(pc, z, 4.16666666666666019037e-02);
+    pc = fma(pc * z, z, fma(z, -0.5, 1.0));
+    const int qi = (int)q;
+    const double ss = (qi & 1) ? pc : ps;
+    const double cc = (qi & 1) ? ps : pc;
+    s = (qi & 2) ? -ss : ss;
+    c = ((qi + 1) & 2) ? -cc : cc;
+}
 IRS_HD float irs_sin(float x) { float s, c; irs_sincos(x, s, c); return s; }
 IRS_HD float irs_cos(float x) { float s, c; irs_sincos(x, s, c); return c; }
-IRS_HD double irs_sin(double x) { return sin(x); }
-IRS_HD double irs_cos(double x) { return cos(x); }
+IRS_HD double irs_sin(double x) { double s, c; irs_sincos(x, s, c); return s; }
+IRS_HD double irs_cos(double x) { double s, c; irs_sincos(x, s, c); return c; }
 
 template <typename T, int K> IRS_HD Dual<T, K> make_const(T v) {
     Dual<T, K> r;

@@ -40,17 +40,44 @@ struct RiccatiLds {
     double H[M * M], R[M * M];
     double p[N], c[N], qv[N], xd[N], g[M], kt[M];
     int bad;
+    unsigned char ti[N * (N + 1) / 2], tj[N * (N + 1) / 2];
 };
+
+// 1/d to ~1 ulp: hardware reciprocal + two Newton steps (a correctly rounded f64 divide
+// is ~40 dependent instructions on the critical path of every Riccati step).
+__device__ __forceinline__ double fast_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
 
 // Backward pass.  On return K (T,M,N) / k (T,M) are in global memory.
 template <int N, int M>
 __device__ __forceinline__ void riccati_backward(const RiccatiArgs& a, int lane, RiccatiLds<N, M>& S) {
-    constexpr int NN = N * N, NM = N * M;
-    constexpr int RA = (NN + 63) / 64, RB = (NM + 63) / 64;
+    constexpr int NN = N * N, NM = N * M, NT = N * (N + 1) / 2;
+    constexpr int RA = (NN + 63) / 64, RB = (NM + 63) / 64, RT = (NT + 63) / 64;
     const int T = a.T;
 
-    for (int q = lane; q < NN; q += 64) { S.P[q] = a.Qd[q]; S.Q[q] = a.Q[q]; }
-    for (int q = lane; q < M * M; q += 64) S.R[q] = a.alpha * a.R[q];
+    // only the symmetric parts of Q, Qd, R enter a quadratic form
+    for (int q = lane; q < NN; q += 64) {
+        int i = q / N, j = q % N;
+        S.P[q] = 0.5 * (a.Qd[q] + a.Qd[j * N + i]);
+        S.Q[q] = 0.5 * (a.Q[q] + a.Q[j * N + i]);
+    }
+    for (int q = lane; q < M * M; q += 64) {
+        int i = q / M, j = q % M;
+        S.R[q] = 0.5 * a.alpha * (a.R[q] + a.R[j * M + i]);
+    }
+    // (i,j), i <= j, of the q-th upper-triangular element
+    for (int q = lane; q < NN; q += 64) {
+        int i = q / N, j = q % N;
+        if (i <= j) {
+            int idx = i * N - i * (i - 1) / 2 + (j - i);
+            S.ti[idx] = (unsigned char)i;
+            S.tj[idx] = (unsigned char)j;
+        }
+    }
     if (lane == 0) S.bad = 0;
     // step T-1 operands
     {
@@ -139,7 +166,7 @@ __device__ __forceinline__ void riccati_backward(const RiccatiArgs& a, int lane,
                 for (int l = 0; l < j; ++l) dj -= Lm[j][l] * Lm[j][l] * Dg[l];
                 ok = ok && (dj > 0.0);
                 Dg[j] = dj;
-                Dinv[j] = 1.0 / dj;
+                Dinv[j] = fast_rcp(dj);
 #pragma unroll
                 for (int i = j + 1; i < M; ++i) {
                     double s = S.H[i * M + j];
@@ -209,19 +236,19 @@ __device__ __forceinline__ void riccati_backward(const RiccatiArgs& a, int lane,
             for (int l = 0; l < N; ++l) pnew += S.Acl[l * N + lane] * S.qv[l] - S.Q[lane * N + l] * S.xd[l];
         }
         wave_sync();
-        // 6. P = Q + sym(A'W); rotate in the prefetched operands of step t-1
+        // 6. P = Q + A'W.  A'P(A+BK) is symmetric: only the upper triangle is computed
+        //    and mirrored (exact symmetry, half the work).  Then rotate in the prefetched
+        //    operands of step t-1.
 #pragma unroll
-        for (int r = 0; r < RA; ++r) {
+        for (int r = 0; r < RT; ++r) {
             int q = lane + 64 * r;
-            if (q < NN) {
-                int i = q / N, j = q % N;
-                double s = 0.0, s2 = 0.0;
+            if (q < NT) {
+                int i = S.ti[q], j = S.tj[q];
+                double s = S.Q[i * N + j];
 #pragma unroll
-                for (int l = 0; l < N; ++l) {
-                    s += S.A[l * N + i] * S.W[l * N + j];
-                    s2 += S.A[l * N + j] * S.W[l * N + i];
-                }
-                S.P[q] = S.Q[q] + 0.5 * (s + s2);
+                for (int l = 0; l < N; ++l) s += S.A[l * N + i] * S.W[l * N + j];
+                S.P[i * N + j] = s;
+                S.P[j * N + i] = s;
             }
         }
         if (lane < N) S.p[lane] = pnew;
@@ -328,7 +355,7 @@ __device__ __forceinline__ void riccati_backward_reg(const RiccatiArgs& a, int l
             for (int l = 0; l < j; ++l) dj -= Lm[j][l] * Lm[j][l] * Dg[l];
             if (!(dj > 0.0) && bad == 0) bad = t + 1;
             Dg[j] = dj;
-            Dinv[j] = 1.0 / dj;
+            Dinv[j] = fast_rcp(dj);
 #pragma unroll
             for (int i = j + 1; i < M; ++i) {
                 double s = H[i][j];
@@ -739,7 +766,24 @@ __device__ __forceinline__ void rollout_device(const ModelParams& p, int T, cons
         if (lane >= m && lane < m + n) rv = xd_trj[(size_t)t * n + (lane - m)];
     };
     fetch(0);
+    // Lane-distributed bookkeeping: lane i < m owns u_i and the i-th row of u'Ru, lane
+    // i < n owns the i-th row of e'Qe; each lane accumulates its share of the cost over
+    // all t and the wave is reduced ONCE at the end.  Only the dynamics step is redundant.
     double cost = 0.0;
+    auto pick = [&](const double* v, int len) {       // v[lane] without dynamic register indexing
+        double r = v[0];
+#pragma unroll
+        for (int i = 1; i < (n > m ? n : m); ++i) r = (i < len && i == lane) ? v[i] : r;
+        return r;
+    };
+    auto state_cost = [&](const double* xdv) {        // lane i < n: e_i * (Q e)_i
+        if (lane < n) {
+            double r = 0.0;
+#pragma unroll
+            for (int j = 0; j < n; ++j) r += S.Q[lane * n + j] * (x[j] - xdv[j]);
+            cost += (pick(x, n) - xdv[lane]) * r;
+        }
+    };
     for (int t = 0; t < T; ++t) {
         wave_sync();
         if (K != nullptr) {
@@ -750,25 +794,23 @@ __device__ __forceinline__ void rollout_device(const ModelParams& p, int T, cons
         if (lane >= m && lane < m + n) S.xd[lane - m] = rv;
         wave_sync();
         fetch(t + 1 < T ? t + 1 : t);
-        if (K != nullptr) {
+        if (lane < m) {
+            double s = S.k[lane];
+            if (K != nullptr) {
 #pragma unroll
-            for (int i = 0; i < m; ++i) {
-                double s = S.k[i];
-#pragma unroll
-                for (int j = 0; j < n; ++j) s += S.K[i * n + j] * x[j];
-                u[i] = s;
+                for (int j = 0; j < n; ++j) s += S.K[lane * n + j] * x[j];
             }
-        } else {
-#pragma unroll
-            for (int i = 0; i < m; ++i) u[i] = S.k[i];
+            S.u[lane] = s;
         }
-        cost += quad_err<n>(S.Q, x, S.xd);
+        state_cost(S.xd);
+        wave_sync();
 #pragma unroll
-        for (int i = 0; i < m; ++i) {
+        for (int i = 0; i < m; ++i) u[i] = S.u[i];
+        if (lane < m) {
             double r = 0.0;
 #pragma unroll
-            for (int j = 0; j < m; ++j) r += S.R[i * m + j] * u[j];
-            cost += u[i] * r;
+            for (int j = 0; j < m; ++j) r += S.R[lane * m + j] * u[j];
+            cost += pick(u, m) * r;
         }
         Model::template step<double>(p, x, u, xn);
 #pragma unroll
@@ -783,10 +825,12 @@ __device__ __forceinline__ void rollout_device(const ModelParams& p, int T, cons
         }
     }
     // terminal term uses Q, not Qd (irs_lqr/irs_lqr.py:135-136)
-    double xdT[n];
+    wave_sync();
+    if (lane < n) S.xd[lane] = xd_trj[(size_t)T * n + lane];
+    wave_sync();
+    state_cost(S.xd);
 #pragma unroll
-    for (int i = 0; i < n; ++i) xdT[i] = xd_trj[(size_t)T * n + i];
-    cost += quad_err<n>(S.Q, x, xdT);
+    for (int sft = 32; sft >= 1; sft >>= 1) cost += __shfl_xor(cost, sft, 64);
     if (lane == 0) cost_out[0] = cost;
 }
 

@@ -152,6 +152,27 @@ class DeviceModel:
               "irs_tvlqr_descent")
         return o
 
+    # ---- CEM baseline -------------------------------------------------------
+    def cem_rollout_costs(self, u_cand, x0, Q, R, xd_trj):
+        """costs (B) of the B candidate sequences u_cand (B,T,m): rollout + evaluate_cost each."""
+        B, T = u_cand.shape[0], u_cand.shape[1]
+        costs = torch.empty((B,), dtype=F64, device=u_cand.device)
+        check(self.lib.irs_cem_rollout_costs(self.model_id, self._p, self._np, T, B, _ptr(u_cand, F64),
+                                             _ptr(x0, F64), _ptr(Q, F64), _ptr(R, F64), _ptr(xd_trj, F64),
+                                             _ptr(costs, F64), _stream()), "irs_cem_rollout_costs")
+        return costs
+
+    def cem_refit(self, u_cand, costs, n_elite):
+        """Elite selection + mean/std refit: returns elite_idx (n_elite), u_new (T,m), std_new (T,m)."""
+        B, T, m = u_cand.shape
+        dev = u_cand.device
+        idx = torch.empty((n_elite,), dtype=torch.int32, device=dev)
+        u_new = torch.empty((T, m), dtype=F64, device=dev)
+        std_new = torch.empty((T, m), dtype=F64, device=dev)
+        check(self.lib.irs_cem_refit(T, m, B, int(n_elite), _ptr(u_cand, F64), _ptr(costs, F64), idx.data_ptr(),
+                                     _ptr(u_new, F64), _ptr(std_new, F64), _stream()), "irs_cem_refit")
+        return idx, u_new, std_new
+
     def smooth_accumulate(self, mode, x_trj, u_trj, dx, du, sums=None):
         """Sample pass on supplied samples: dx (T,N,n) f32 (None for ZERO_ORDER_B), du (T,N,m) f32."""
         T, N = du.shape[0], du.shape[1]

@@ -28,7 +28,14 @@ def shard_range(N, rank, world):
 
 
 def all_reduce_sums(sums, group=None):
-    """In-place SUM all-reduce of the (T,P) statistics; no-op for a single rank."""
+    """In-place SUM all-reduce of the (T,P) statistics; no-op for a single rank.
+    `nccl` (= RCCL on ROCm) reduces the device tensor in place over xGMI; with the `gloo`
+    backend (CPU rehearsals of the N>1 path) a device tensor is staged through the host."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        if sums.is_cuda and dist.get_backend(group) == "gloo":
+            host = sums.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            sums.copy_(host)
+        else:
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
     return sums

@@ -471,3 +471,76 @@ def test_error_behaviour(amd):
 
     with pytest.raises(RuntimeError, match="Could not evaluate dynamics"):
         amd.IrsLqrExact(NoDevice(), pend_params(amd, 5))
+
+
+# ---------------------------------------------------------------- CEM baseline (irs_lqr/cem.py)
+def cem_params(amd, T, B, n_elite):
+    p = amd.CemParameters()
+    p.Q, p.Qd, p.R = np.diag([1., 1.]), np.diag([20., 20.]), np.diag([1.])
+    p.x0 = np.array([0., 0.])
+    p.xd_trj = np.tile(np.array([np.pi, 0.]), (T + 1, 1))
+    p.u_trj_initial = np.tile(np.array([0.1]), (T, 1))
+    p.initial_std = np.array([1.0])
+    p.batch_size, p.n_elite = B, n_elite
+    return p
+
+
+def test_cem_local_descent_vs_reference_fixture(amd, golden_dir):
+    """Identical seed as the reference run that produced the fixture (cem.py:151-184)."""
+    f = load(golden_dir, "pendulum_cem_T30_B50")
+    cem = amd.CrossEntropyMethod(amd.PendulumDynamics(float(f["h"])), cem_params(amd, 30, 50, int(f["n_elite"])))
+    np.random.seed(int(f["seed"]))
+    x_new, u_new = cem.local_descent(cem.x_trj, cem.u_trj)
+    np.testing.assert_allclose(u_new, f["u_new"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(cem.std_trj, f["std_new"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(x_new, f["x_new"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("name,T,B,n_elite", [("pendulum", 30, 5000, 50), ("quadrotor", 20, 3000, 7),
+                                              ("pendulum", 5, 3, 3), ("pendulum", 80, 50000, 2500)])
+def test_cem_step_vs_oracle(amd, name, T, B, n_elite):
+    from irs_mpc_amd import device as dev
+    sys_d, sys_o = systems(amd, name)
+    n, m = sys_o.dim_x, sys_o.dim_u
+    params = (pend_params if name == "pendulum" else quad_params)(amd, T)
+    rng = np.random.default_rng(B)
+    cand = params.u_trj_initial + (0.5 if name == "pendulum" else 0.05) * rng.normal(size=(B, T, m))
+    dm = sys_d.dm()
+    Q, R, xd, x0 = (dev.to_dev(a) for a in (params.Q, params.R, params.xd_trj, params.x0))
+    cd = dev.to_dev(cand)
+    costs = dm.cem_rollout_costs(cd, x0, Q, R, xd)
+    idx, u_new, std_new = dm.cem_refit(cd, costs, n_elite)
+    check = min(B, 400)        # the oracle's Python rollouts are slow: verify a subset of costs ...
+    sel = rng.choice(B, check, replace=False)
+    co = np.array([orc.evaluate_cost(orc.rollout(sys_o, params.x0, cand[b]), cand[b], params.xd_trj, params.Q,
+                                     params.R) for b in sel])
+    np.testing.assert_allclose(costs.cpu().numpy()[sel], co, rtol=1e-11)
+    # ... and the selection + refit against NumPy on the device's own costs
+    ch = costs.cpu().numpy()
+    best = np.argpartition(ch, n_elite - 1)[:n_elite] if n_elite < B else np.arange(B)
+    assert sorted(idx.cpu().numpy().tolist()) == sorted(best.tolist())
+    np.testing.assert_allclose(u_new.cpu().numpy(), cand[best].mean(axis=0), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(std_new.cpu().numpy(), cand[best].std(axis=0), rtol=1e-9, atol=1e-12)
+
+
+def test_cem_select_ties_and_nan(amd):
+    """Equal costs at the threshold: lowest indices win; NaN costs are never elite."""
+    from irs_mpc_amd import device as dev
+    dm = amd.PendulumDynamics(0.05).dm()
+    costs = np.array([5., 1., 3., 3., np.nan, 3., 0.5, 3., 9., -2.])
+    cand = np.arange(10, dtype=float).reshape(10, 1, 1)
+    idx, u_new, std_new = dm.cem_refit(dev.to_dev(cand), dev.to_dev(costs), 5)
+    assert sorted(idx.cpu().numpy().tolist()) == [1, 2, 3, 6, 9]
+    np.testing.assert_allclose(u_new.cpu().numpy().ravel(), [np.mean([1, 2, 3, 6, 9])])
+    idx, _, _ = dm.cem_refit(dev.to_dev(cand), dev.to_dev(costs), 9)
+    assert 4 not in idx.cpu().numpy().tolist()
+
+
+def test_cem_iterate_reduces_cost(amd):
+    cem = amd.CrossEntropyMethod(amd.PendulumDynamics(0.05), cem_params(amd, 30, 2000, 20))
+    cem.verbose = False
+    np.random.seed(0)
+    cem.iterate(5)
+    assert len(cem.cost_lst) == 7
+    assert all(b < a for a, b in zip(cem.cost_lst, cem.cost_lst[1:]))      # monotone descent here
+    assert cem.cost_lst[-1] < 0.92 * cem.cost_lst[0]
