@@ -47,8 +47,11 @@ typedef enum irs_status {
  * functors (irs_lqr/dynamical_system.py:1-66).                                  */
 typedef enum irs_model_id {
     IRS_MODEL_PENDULUM = 0,   /* examples/pendulum/pendulum_dynamics.py:8-127; params = {h}            */
-    IRS_MODEL_QUADROTOR = 1   /* examples/quadrotor/quadrotor_dynamics.py:15-231;
+    IRS_MODEL_QUADROTOR = 1,  /* examples/quadrotor/quadrotor_dynamics.py:15-231;
                                  params = {h, m, L, g, Ixx, Iyy, Izz, kF, kM}                          */
+    IRS_MODEL_BICYCLE = 2,    /* examples/bicycle/bicycle_dynamics.py:8-132; params = {h}              */
+    IRS_MODEL_THREE_CART = 3  /* examples/three_cart/three_cart_dynamics.py:8-107 (scalar `dynamics`:
+                                 contact by branching); params = {h, d}                                */
 } irs_model_id;
 
 /* Smoothing estimators.                                                         */

@@ -14,6 +14,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libirs_hip.so")
 IRS_OK = 0
 MODEL_PENDULUM = 0
 MODEL_QUADROTOR = 1
+MODEL_BICYCLE = 2
+MODEL_THREE_CART = 3
 SMOOTH_ZERO_ORDER_AB = 0
 SMOOTH_FIRST_ORDER = 1
 SMOOTH_ZERO_ORDER_B = 2

@@ -15,6 +15,10 @@ struct Dual {
 };
 
 template <typename T> struct scalar_of { using type = T; };
+// underlying value (for branch conditions of non-smooth models)
+IRS_HD float irs_value(float x) { return x; }
+IRS_HD double irs_value(double x) { return x; }
+template <typename T, int K> IRS_HD T irs_value(const Dual<T, K>& x) { return x.v; }
 template <typename T, int K> struct scalar_of<Dual<T, K>> { using type = T; };
 
 // f32 sine/cosine for the sample pass: branch-free (no large-argument slow path, so the

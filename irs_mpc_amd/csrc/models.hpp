@@ -83,6 +83,63 @@ struct QuadrotorModel {
     }
 };
 
+// examples/bicycle/bicycle_dynamics.py:47-64 -- explicit Euler on a kinematic bicycle;
+// x = [x, y, heading, speed, steering angle], u = [acceleration, steering velocity].
+struct BicycleModel {
+    static constexpr int NX = 5, NU = 2, NPARAMS = 1;
+    template <typename S>
+    IRS_HD static void step(const ModelParams& p, const S* x, const S* u, S* xn) {
+        using T = typename scalar_of<S>::type;
+        const T h = T(p.v[0]);
+        S sh, ch, ss, cs;
+        irs_sincos(x[2], sh, ch);
+        irs_sincos(x[4], ss, cs);
+        xn[0] = x[0] + h * (x[3] * ch);
+        xn[1] = x[1] + h * (x[3] * sh);
+        xn[2] = x[2] + h * (x[3] * (ss / cs));
+        xn[3] = x[3] + h * u[0];
+        xn[4] = x[4] + h * u[1];
+    }
+};
+
+// examples/three_cart/three_cart_dynamics.py:22-107 -- three carts on a line, perfectly
+// inelastic contact resolved by branching; x = [q1,q2,q3,v1,v2,v3], u = [u1,u3],
+// params = {h, d (cart width)}.  The scalar `dynamics` is followed (penetration split in
+// halves); the reference's `dynamics_batch` (:175-188) moves each cart by the full depth.
+// Non-smooth: Jacobians (dual numbers) are those of the active branch.
+struct ThreeCartModel {
+    static constexpr int NX = 6, NU = 2, NPARAMS = 2;
+    template <typename S>
+    IRS_HD static void step(const ModelParams& p, const S* x, const S* u, S* xn) {
+        using T = typename scalar_of<S>::type;
+        const T h = T(p.v[0]), d = T(p.v[1]);
+        // :32-40 semi-implicit velocity then position update
+        S v1 = x[3] + h * u[0], v2 = x[4], v3 = x[5] + h * u[1];
+        S q1 = x[0] + h * v1, q2 = x[1] + h * v2, q3 = x[2] + h * v3;
+        const bool c12 = irs_value(q2 - q1) < d;
+        const bool c23 = irs_value(q3 - q2) < d;
+        if (c12 && c23) {                       // :48-62 all three stick together
+            S qm = (q1 + q2 + q3) * T(1.0 / 3.0);
+            S vm = (v1 + v2 + v3) * T(1.0 / 3.0);
+            xn[0] = qm - d; xn[1] = qm; xn[2] = qm + d;
+            xn[3] = vm; xn[4] = vm; xn[5] = vm;
+        } else if (c12) {                       // :64-78 carts 1-2 collide
+            S pen = d - (q2 - q1);
+            S vm = (v1 + v2) * T(0.5);
+            xn[0] = q1 - T(0.5) * pen; xn[1] = q2 + T(0.5) * pen; xn[2] = q3;
+            xn[3] = vm; xn[4] = vm; xn[5] = v3;
+        } else if (c23) {                       // :80-94 carts 2-3 collide
+            S pen = d - (q3 - q2);
+            S vm = (v2 + v3) * T(0.5);
+            xn[0] = q1; xn[1] = q2 - T(0.5) * pen; xn[2] = q3 + T(0.5) * pen;
+            xn[3] = v1; xn[4] = vm; xn[5] = vm;
+        } else {                                // :96-104 free motion
+            xn[0] = q1; xn[1] = q2; xn[2] = q3;
+            xn[3] = v1; xn[4] = v2; xn[5] = v3;
+        }
+    }
+};
+
 // J (n x (n+m), row-major) = d step / d [x,u] at (x,u), T = float or double.
 template <class Model, typename T>
 IRS_HD void model_jacobian(const ModelParams& p, const T* x, const T* u, T* xn, T* J) {

@@ -799,6 +799,8 @@ int irs_rng_samples(int n, int m, int T, int N, const double* std_x, const doubl
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (n == 2 && m == 1) hipLaunchKernelGGL((rng_samples_kernel<2, 1>), grid, block, 0, st, dx, du, a);
     else if (n == 12 && m == 4) hipLaunchKernelGGL((rng_samples_kernel<12, 4>), grid, block, 0, st, dx, du, a);
+    else if (n == 5 && m == 2) hipLaunchKernelGGL((rng_samples_kernel<5, 2>), grid, block, 0, st, dx, du, a);
+    else if (n == 6 && m == 2) hipLaunchKernelGGL((rng_samples_kernel<6, 2>), grid, block, 0, st, dx, du, a);
     else { irs_set_error("irs_rng_samples: unsupported (n,m)=(%d,%d)", n, m); return IRS_ERR_UNSUPPORTED; }
     IRS_CHECK_LAUNCH();
     return IRS_OK;

@@ -176,7 +176,103 @@ class QuadrotorOracle:
         return np.stack([self.jacobian_xu(x[i], u[i]) for i in range(x.shape[0])])
 
 
-SYSTEMS = {"pendulum": PendulumOracle, "quadrotor": QuadrotorOracle}
+class BicycleOracle:
+    """examples/bicycle/bicycle_dynamics.py:8-132."""
+
+    name = "bicycle"
+
+    def __init__(self, h):
+        self.h = h
+        self.dim_x = 5
+        self.dim_u = 2
+
+    def dynamics(self, x, u):
+        # bicycle_dynamics.py:47-64
+        heading, v, steer = x[2], x[3], x[4]
+        dxdt = np.array([v * np.cos(heading), v * np.sin(heading), v * np.tan(steer), u[0], u[1]])
+        return x + self.h * dxdt
+
+    def dynamics_batch(self, x, u):
+        # bicycle_dynamics.py:66-87
+        heading, v, steer = x[:, 2], x[:, 3], x[:, 4]
+        dxdt = np.vstack((v * np.cos(heading), v * np.sin(heading), v * np.tan(steer),
+                          u[:, 0], u[:, 1])).transpose()
+        return x + self.h * dxdt
+
+    def jacobian_xu(self, x, u):
+        # bicycle_dynamics.py:115-122 evaluates the symbolic Jacobian of dynamics_sym (:26-44)
+        h, th, v, st = self.h, x[2], x[3], x[4]
+        J = np.zeros((5, 7))
+        J[:, :5] = np.eye(5)
+        J[0, 2], J[0, 3] = -h * v * np.sin(th), h * np.cos(th)
+        J[1, 2], J[1, 3] = h * v * np.cos(th), h * np.sin(th)
+        J[2, 3], J[2, 4] = h * np.tan(st), h * v / np.cos(st) ** 2
+        J[3, 5] = h
+        J[4, 6] = h
+        return J
+
+    def jacobian_xu_batch(self, x, u):
+        return np.stack([self.jacobian_xu(x[i], u[i]) for i in range(x.shape[0])])
+
+
+class ThreeCartOracle:
+    """examples/three_cart/three_cart_dynamics.py:8-107 (the scalar `dynamics`)."""
+
+    name = "three_cart"
+
+    def __init__(self, h):
+        self.h = h
+        self.dim_x = 6
+        self.dim_u = 2
+        self.d = 0.2
+
+    def dynamics(self, x, u):
+        # three_cart_dynamics.py:22-107
+        q1, q2, q3, v1, v2, v3 = x
+        u1, u3 = u
+        v1s, v2s, v3s = v1 + self.h * u1, v2, v3 + self.h * u3
+        q1s, q2s, q3s = q1 + self.h * v1s, q2 + self.h * v2s, q3 + self.h * v3s
+        if (q2s - q1s < self.d) and (q3s - q2s < self.d):
+            q2n = (1. / 3.) * (q1s + q2s + q3s)
+            q1n, q3n = q2n - self.d, q2n + self.d
+            v1n = v2n = v3n = (1. / 3.) * (v1s + v2s + v3s)
+        elif q2s - q1s < self.d:
+            pen = self.d - (q2s - q1s)
+            q2n, q1n = q2s + 0.5 * pen, q1s - 0.5 * pen
+            v1n = v2n = 0.5 * (v1s + v2s)
+            q3n, v3n = q3s, v3s
+        elif q3s - q2s < self.d:
+            pen = self.d - (q3s - q2s)
+            q3n, q2n = q3s + 0.5 * pen, q2s - 0.5 * pen
+            v2n = v3n = 0.5 * (v2s + v3s)
+            q1n, v1n = q1s, v1s
+        else:
+            q1n, q2n, q3n, v1n, v2n, v3n = q1s, q2s, q3s, v1s, v2s, v3s
+        return np.array([q1n, q2n, q3n, v1n, v2n, v3n])
+
+    def dynamics_batch(self, x, u):
+        """Row-wise scalar dynamics (what the device functor implements; the reference's
+        own dynamics_batch, :109-203, resolves penetration by the full depth instead)."""
+        return np.stack([self.dynamics(x[b], u[b]) for b in range(x.shape[0])])
+
+    def jacobian_xu(self, x, u):
+        """Derivative of the active branch (central differences are exact for a
+        piecewise-linear map away from the switching surfaces)."""
+        n, d = 6, 8
+        xu = np.hstack((x, u))
+        J = np.zeros((n, d))
+        for j in range(d):
+            e = np.zeros(d)
+            e[j] = 1e-7
+            J[:, j] = (self.dynamics((xu + e)[:n], (xu + e)[n:]) - self.dynamics((xu - e)[:n], (xu - e)[n:])) / 2e-7
+        return J
+
+    def jacobian_xu_batch(self, x, u):
+        return np.stack([self.jacobian_xu(x[i], u[i]) for i in range(x.shape[0])])
+
+
+SYSTEMS = {"pendulum": PendulumOracle, "quadrotor": QuadrotorOracle, "bicycle": BicycleOracle,
+           "three_cart": ThreeCartOracle}
 
 
 # --------------------------------------------------------------------------

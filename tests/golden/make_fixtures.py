@@ -173,6 +173,52 @@ def main():
         h=0.05, x_trj=sol.x_trj, u_trj=sol.u_trj, cost0=sol.cost,
         dx=np.stack(rec.dx), du=np.stack(rec.du), At=At, Bt=Bt, ct=ct, seed=2)
 
+    # ---------------- bicycle (examples/bicycle) ----------------
+    sys.path.insert(0, os.path.join(REF, "examples", "bicycle"))
+    sys.path.insert(0, os.path.join(REF, "examples", "three_cart"))
+    from bicycle_dynamics import BicycleDynamics
+    from three_cart_dynamics import ThreeCartDynamics
+    bike = BicycleDynamics.__new__(BicycleDynamics)      # __init__ needs pydrake.symbolic
+    bike.h, bike.dim_x, bike.dim_u = 0.1, 5, 2
+    rng = np.random.default_rng(4)
+    X = rng.normal(size=(48, 5)) * np.array([2., 2., 1., 2., 0.3])
+    U = rng.normal(size=(48, 2))
+    out["bicycle_dynamics"] = dict(h=0.1, X=X, U=U, Xn=bike.dynamics_batch(X, U),
+                                   Xn_scalar=np.stack([bike.dynamics(X[i], U[i]) for i in range(48)]))
+
+    def bike_params(T, xd):        # bicycle_zero_order.py:16-31 ("easy"); "hard" differs in xd
+        p = IrsLqrParameters()
+        p.Q = np.diag([5, 5, 3, 0.1, 0.1])
+        p.Qd = np.diag([50, 50, 30, 1, 1]).astype(float)
+        p.R = np.diag([1, 0.1])
+        p.x0 = np.zeros(5)
+        p.xd_trj = np.tile(np.asarray(xd, float), (T + 1, 1))
+        p.u_trj_initial = np.tile(np.array([0.1, 0.0]), (T, 1))
+        p.xbound = None
+        p.ubound = None
+        return p
+
+    s_b = IrsLqr(bike, bike_params(100, [3.0, 1.0, np.pi / 2, 0, 0]))
+    out["bicycle_T100_init"] = dict(cost0=s_b.cost, x_trj=s_b.x_trj)
+    rec = Recorder(200, np.array([2.0, 2.0, 1.0, 2.0, 0.01]), np.array([2.0, 1.0]), 5, 2)
+    np.random.seed(4)
+    sol = IrsLqrZeroOrder(bike, bike_params(8, [3.0, 1.0, np.pi / 2, 0, 0]), rec)
+    At, Bt, ct = sol.get_TV_matrices(sol.x_trj, sol.u_trj)
+    out["bicycle_zero_T8_N200"] = dict(h=0.1, x_trj=sol.x_trj, u_trj=sol.u_trj, dx=np.stack(rec.dx),
+                                       du=np.stack(rec.du), At=At, Bt=Bt, ct=ct, seed=4)
+
+    # ---------------- three_cart: scalar dynamics, all four contact branches ----------------
+    carts = ThreeCartDynamics(0.05)
+    rng = np.random.default_rng(5)
+    X = np.zeros((80, 6))
+    X[:, 0] = rng.normal(size=80) * 0.3
+    X[:, 1] = X[:, 0] + 0.2 + rng.normal(size=80) * 0.15      # gaps straddle the cart width 0.2
+    X[:, 2] = X[:, 1] + 0.2 + rng.normal(size=80) * 0.15
+    X[:, 3:] = rng.normal(size=(80, 3))
+    U = rng.normal(size=(80, 2))
+    Xn = np.stack([carts.dynamics(X[i], U[i]) for i in range(80)])
+    out["three_cart_dynamics"] = dict(h=0.05, X=X, U=U, Xn_scalar=Xn)
+
     # ---------------- CEM (irs_lqr/cem.py) on the pendulum ----------------
     from irs_lqr.cem import CemParameters, CrossEntropyMethod
     T = 30

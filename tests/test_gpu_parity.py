@@ -70,7 +70,7 @@ class Replay:
         self.dx, self.du, self.i = dx, du, 0
 
     def __call__(self, x, u, it):
-        i = self.i
+        i = self.i % len(self.dx)       # a second pass replays the same draws
         self.i += 1
         return self.dx[i], self.du[i]
 
@@ -471,6 +471,89 @@ def test_error_behaviour(amd):
 
     with pytest.raises(RuntimeError, match="Could not evaluate dynamics"):
         amd.IrsLqrExact(NoDevice(), pend_params(amd, 5))
+
+
+# ---------------------------------------------------------------- bicycle / three_cart device models
+def bike_params(amd, T):
+    p = amd.IrsLqrParameters()
+    p.Q, p.Qd, p.R = np.diag([5, 5, 3, 0.1, 0.1]), np.diag([50., 50, 30, 1, 1]), np.diag([1, 0.1])
+    p.x0 = np.zeros(5)
+    p.xd_trj = np.tile(np.array([3.0, 1.0, np.pi / 2, 0, 0]), (T + 1, 1))
+    p.u_trj_initial = np.tile(np.array([0.1, 0.0]), (T, 1))
+    return p
+
+
+def cart_params(amd, T):
+    p = amd.IrsLqrParameters()
+    p.Q = 0.01 * np.diag([50., 50, 50, 20, 100, 20])
+    p.Qd = np.diag([50., 50, 50, 20, 100, 20])
+    p.R = 0.01 * np.eye(2)
+    p.x0 = np.array([0., 1, 2, 0, 0, 0])
+    p.xd_trj = np.tile(np.array([2., 3, 4, 0, 0, 0]), (T + 1, 1))
+    p.u_trj_initial = np.tile(np.array([0.1, -0.1]), (T, 1))
+    return p
+
+
+def test_bicycle_vs_reference_fixtures(amd, golden_dir):
+    f = load(golden_dir, "bicycle_dynamics")
+    bike = amd.BicycleDynamics(float(f["h"]))
+    np.testing.assert_allclose(bike.dynamics_batch(f["X"], f["U"]), f["Xn"], rtol=0, atol=1e-12)
+    so = orc.BicycleOracle(0.1)
+    np.testing.assert_allclose(bike.jacobian_xu_batch(f["X"], f["U"]), so.jacobian_xu_batch(f["X"], f["U"]),
+                               rtol=1e-12, atol=1e-12)
+    g = load(golden_dir, "bicycle_T100_init")
+    sol = amd.IrsLqrExact(bike, bike_params(amd, 100))
+    np.testing.assert_allclose(sol.x_trj, g["x_trj"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(sol.cost, float(g["cost0"]), rtol=1e-13)       # 3302.0894 of the reference CSVs
+    z = load(golden_dir, "bicycle_zero_T8_N200")
+    sol = amd.IrsLqrZeroOrder(bike, bike_params(amd, 8), Replay(z["dx"], z["du"]))
+    At, Bt, ct = sol.get_TV_matrices(sol.x_trj, sol.u_trj)
+    # x_initial_var mixes std 2.0 and 0.01 columns (bicycle_zero_order.py:34): the Jacobi
+    # scaling keeps the normal equations well conditioned
+    np.testing.assert_allclose(At, z["At"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(Bt, z["Bt"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(ct, z["ct"], rtol=2e-4, atol=2e-4)
+
+
+def test_three_cart_vs_reference_fixture(amd, golden_dir):
+    f = load(golden_dir, "three_cart_dynamics")
+    carts = amd.ThreeCartDynamics(float(f["h"]))
+    np.testing.assert_allclose(carts.dynamics_batch(f["X"], f["U"]), f["Xn_scalar"], rtol=0, atol=1e-13)
+    so = orc.ThreeCartOracle(0.05)
+    np.testing.assert_allclose(carts.jacobian_xu_batch(f["X"], f["U"]), so.jacobian_xu_batch(f["X"], f["U"]),
+                               rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("name,T,N", [("bicycle", 20, 4000), ("three_cart", 20, 4000)])
+def test_new_models_smoothing_and_descent_vs_oracle(amd, name, T, N):
+    sys_d = amd.BicycleDynamics(0.1) if name == "bicycle" else amd.ThreeCartDynamics(0.05)
+    sys_o = orc.BicycleOracle(0.1) if name == "bicycle" else orc.ThreeCartOracle(0.05)
+    params = (bike_params if name == "bicycle" else cart_params)(amd, T)
+    n, m = sys_o.dim_x, sys_o.dim_u
+    rng = np.random.default_rng(7)
+    dx = (rng.normal(size=(T, N, n)) * 0.3).astype(np.float32)
+    du = (rng.normal(size=(T, N, m)) * 0.3).astype(np.float32)
+    sol = amd.IrsLqrZeroOrder(sys_d, params, Replay(dx, du))
+    sol.verbose = False
+    At, Bt, ct = sol.get_TV_matrices(sol.x_trj, sol.u_trj)
+    Ao, Bo, co = orc.zero_order_TV(sys_o, sol.x_trj, sol.u_trj, dx.astype(np.float64), du.astype(np.float64))
+    np.testing.assert_allclose(At, Ao, rtol=2e-4, atol=1e-4)
+    np.testing.assert_allclose(Bt, Bo, rtol=2e-4, atol=1e-4)
+    np.testing.assert_allclose(ct, co, rtol=2e-4, atol=1e-4)
+    if name == "bicycle":       # smooth model: first-order too
+        fo = amd.IrsLqrFirstOrder(sys_d, params, Replay(dx, du))
+        A1, B1, c1 = fo.get_TV_matrices(fo.x_trj, fo.u_trj)
+        A2, B2, c2 = orc.first_order_TV(sys_o, fo.x_trj, fo.u_trj, dx.astype(np.float64), du.astype(np.float64))
+        np.testing.assert_allclose(A1, A2, **TOL_AB)
+        np.testing.assert_allclose(B1, B2, **TOL_AB)
+    # Riccati + closed-loop rollout on the device's own linearisation vs the oracle on the same
+    x_new, u_new = sol.local_descent(sol.x_trj, sol.u_trj)
+    L = sol._last
+    xo, uo, K, k = orc.local_descent(sys_o, L["At"].cpu().numpy(), L["Bt"].cpu().numpy(), L["ct"].cpu().numpy(),
+                                     params.Q, params.Qd, params.R, params.x0, params.xd_trj)
+    np.testing.assert_allclose(L["K"].cpu().numpy(), K, rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(u_new, uo, rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(x_new, xo, rtol=1e-7, atol=1e-8)
 
 
 # ---------------------------------------------------------------- CEM baseline (irs_lqr/cem.py)

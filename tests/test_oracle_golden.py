@@ -104,6 +104,37 @@ def test_cem_fixture(golden_dir):
     np.testing.assert_allclose(x_new, f["x_new"], rtol=0, atol=1e-13)
 
 
+def test_bicycle_fixtures(golden_dir):
+    f = load(golden_dir, "bicycle_dynamics")
+    s = orc.BicycleOracle(float(f["h"]))
+    assert np.array_equal(s.dynamics_batch(f["X"], f["U"]), f["Xn"])
+    for i in range(f["X"].shape[0]):
+        assert np.array_equal(s.dynamics(f["X"][i], f["U"][i]), f["Xn_scalar"][i])
+    # examples/bicycle/bicycle_zero_order.py:11-31 initial trajectory cost
+    # (== first line of examples/bicycle/analysis/bicycle_easy_*.csv: 3302.0894)
+    g = load(golden_dir, "bicycle_T100_init")
+    Q, R = np.diag([5, 5, 3, 0.1, 0.1]), np.diag([1, 0.1])
+    xd = np.tile(np.array([3.0, 1.0, np.pi / 2, 0, 0]), (101, 1))
+    u0 = np.tile(np.array([0.1, 0.0]), (100, 1))
+    x = orc.rollout(s, np.zeros(5), u0)
+    np.testing.assert_allclose(x, g["x_trj"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(orc.evaluate_cost(x, u0, xd, Q, R), float(g["cost0"]), rtol=1e-14)
+    assert abs(float(g["cost0"]) - 3302.0894) < 1e-3
+    z = load(golden_dir, "bicycle_zero_T8_N200")
+    At, Bt, ct = orc.zero_order_TV(s, z["x_trj"], z["u_trj"], z["dx"], z["du"])
+    np.testing.assert_allclose(At, z["At"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(Bt, z["Bt"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(ct, z["ct"], rtol=0, atol=1e-10)
+
+
+def test_three_cart_fixture(golden_dir):
+    """All four contact branches of three_cart_dynamics.py:44-104."""
+    f = load(golden_dir, "three_cart_dynamics")
+    s = orc.ThreeCartOracle(float(f["h"]))
+    for i in range(f["X"].shape[0]):
+        assert np.array_equal(s.dynamics(f["X"][i], f["U"][i]), f["Xn_scalar"][i])
+
+
 # ---- Jacobians: exact derivative vs central differences of the pinned dynamics
 @pytest.mark.parametrize("sysname", ["pendulum", "quadrotor"])
 def test_jacobian_vs_finite_difference(sysname):
