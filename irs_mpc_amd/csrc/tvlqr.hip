@@ -435,16 +435,198 @@ __device__ __forceinline__ void riccati_backward_reg(const RiccatiArgs& a, int l
     if (lane == 0) a.info[0] = bad;
 }
 
+// ------------------------------------------------------------------ matrix-core path
+// 4 < N <= 15, M <= 4 (quadrotor 12/4, bicycle 5/2, three_cart 6/2): the recursion in
+// homogeneous coordinates z = [x; 1],
+//     A~ = [A c; 0 1],  B~ = [B; 0],  P~ = [P p; p' r],  Q~_t = [Q -Q xd_t; -(Q xd_t)' *],
+//     K~ = -(aR + B~'P~B~)^-1 B~'P~A~ = [K | k],     P~ <- Q~_t + A~'P~(A~ + B~K~),
+// carries the affine terms (c, p, k) inside ONE 16x16 tile, and every product chains
+// through v_mfma_f64_16x16x4_f64 in registers: the C/D layout of that instruction
+// (col = lane&15, row = (lane>>4) + 4*reg) IS its B-operand layout (k = (lane>>4) + 4*step),
+// and the A-operand layout of the TRANSPOSE -- so P~ (symmetric), A~' and B~' need no
+// data movement at all.  No LDS traffic, no waits inside a step except the 4x4 solve.
+typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int kQxMax = 4096;          // doubles of LDS for Q xd_t, t = 0..T
+
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
 template <int N, int M>
-__device__ __forceinline__ void riccati_backward_any(const RiccatiArgs& a, int lane, RiccatiLds<N, M>& S) {
-    if constexpr (N <= 4 && M <= 2) riccati_backward_reg<N, M>(a, lane);
-    else riccati_backward<N, M>(a, lane, S);
+__device__ __forceinline__ void riccati_backward_mfma(const RiccatiArgs& a, int lane, double* qx) {
+    static_assert(N + 1 <= 16 && M <= 4, "one 16x16 tile, gains in accumulator register 0");
+    constexpr int KA = (N + 1 + 3) / 4;      // k-steps over the augmented dimension
+    constexpr int KB = (N + 3) / 4;          // k-steps when the operand's rows >= N are zero
+    const int T = a.T;
+    const int col = lane & 15, rg = lane >> 4;
+    auto qs = [&](const double* Qm, int i, int j) { return 0.5 * (Qm[i * N + j] + Qm[j * N + i]); };
+
+    // qx[t][i] = (Q xd_t)_i for every t, once, in parallel
+    for (int idx = lane; idx < (T + 1) * N; idx += 64) {
+        const int t = idx / N, i = idx % N;
+        double s = 0.0;
+        for (int j = 0; j < N; ++j) s += qs(a.Q, i, j) * a.xd[(size_t)t * N + j];
+        qx[idx] = s;
+    }
+    double Rr[M][M];
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) Rr[i][j] = 0.5 * a.alpha * (a.R[i * M + j] + a.R[j * M + i]);
+    v4d Qc, P;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = rg + 4 * r;
+        Qc[r] = (row < N && col < N) ? qs(a.Q, row, col) : 0.0;
+        // P~_T = [Qd, -Qd xd_T; ., 0]
+        double v = 0.0;
+        if (row < N && col < N) v = qs(a.Qd, row, col);
+        else if ((col == N && row < N) || (row == N && col < N)) {
+            const int i = col == N ? row : col;
+            for (int j = 0; j < N; ++j) v -= qs(a.Qd, i, j) * a.xd[(size_t)T * N + j];
+        }
+        P[r] = v;
+    }
+    auto load_step = [&](int t, v4d& Ab, v4d& Bb, double& Ba) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rg + 4 * r;
+            double va = 0.0, vb = 0.0;
+            if (row < N) {
+                if (col < N) va = a.At[((size_t)t * N + row) * N + col];
+                else if (col == N) va = a.ct[(size_t)t * N + row];
+                if (col < M) vb = a.Bt[((size_t)t * N + row) * M + col];
+            } else if (row == N && col == N) {
+                va = 1.0;
+            }
+            Ab[r] = va;
+            Bb[r] = vb;
+        }
+        Ba = (col < N && rg < M) ? a.Bt[((size_t)t * N + col) * M + rg] : 0.0;
+    };
+    v4d An, Bn;
+    double Ban;
+    load_step(T - 1, An, Bn, Ban);
+    wave_sync();                                     // qx visible
+    bool ok = true;
+    int bad_t = 0;
+    for (int t = T - 1; t >= 0; --t) {
+        const v4d Ab = An, Bb = Bn;
+        const double Ba = Ban;
+        load_step(t > 0 ? t - 1 : 0, An, Bn, Ban);   // prefetch
+        v4d Qt = Qc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rg + 4 * r;
+            if (col == N && row < N) Qt[r] = -qx[t * N + row];
+            else if (row == N && col < N) Qt[r] = -qx[t * N + col];
+        }
+        // D1 = P~ A~ , D2 = P~ B~
+        v4d D1 = {0, 0, 0, 0}, D2 = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KA; ++s) {
+            D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[s], Ab[s], D1, 0, 0, 0);
+            D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[s], Bb[s], D2, 0, 0, 0);
+        }
+        // G~ = B~' D1 (rows < M: [B'PA | B'(Pc+p)]),  Hh = B~' D2 = B'PB
+        v4d G = {0, 0, 0, 0}, Hh = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KB; ++s) {
+            G = __builtin_amdgcn_mfma_f64_16x16x4f64(Bb[s], D1[s], G, 0, 0, 0);
+            Hh = __builtin_amdgcn_mfma_f64_16x16x4f64(Bb[s], D2[s], Hh, 0, 0, 0);
+        }
+        // M x M Hessian to every lane (element (i,j) sits in register 0 of lane 16 i + j)
+        double H[M][M];
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int j = 0; j < M; ++j) H[i][j] = Rr[i][j] + readlane_f64(Hh[0], 16 * i + j);
+        double Lm[M][M], Dg[M], Dinv[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            double dj = H[j][j];
+#pragma unroll
+            for (int l = 0; l < j; ++l) dj -= Lm[j][l] * Lm[j][l] * Dg[l];
+            if (!(dj > 0.0) && ok) { ok = false; bad_t = t + 1; }
+            Dg[j] = dj;
+            Dinv[j] = fast_rcp(dj);
+#pragma unroll
+            for (int i = j + 1; i < M; ++i) {
+                double s = H[i][j];
+#pragma unroll
+                for (int l = 0; l < j; ++l) s -= Lm[i][l] * Lm[j][l] * Dg[l];
+                Lm[i][j] = s * Dinv[j];
+            }
+        }
+        // this lane's column of G~ (its M entries live in lanes 16 i + col), solve, keep row rg
+        double y[M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) y[i] = __shfl(G[0], 16 * i + col, 64);
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+#pragma unroll
+            for (int l = 0; l < i; ++l) y[i] -= Lm[i][l] * y[l];
+        }
+#pragma unroll
+        for (int i = M - 1; i >= 0; --i) {
+            double s = y[i] * Dinv[i];
+#pragma unroll
+            for (int l = i + 1; l < M; ++l) s -= Lm[l][i] * y[l];
+            y[i] = s;
+        }
+        double Kb = 0.0;                              // K~[rg][col] = [K | k]
+#pragma unroll
+        for (int i = 0; i < M; ++i) Kb = (i == rg) ? -y[i] : Kb;
+        if (rg >= M || col > N) Kb = 0.0;
+        if (rg < M) {
+            if (col < N) a.K[((size_t)t * M + rg) * N + col] = Kb;
+            else if (col == N) a.k[(size_t)t * M + rg] = Kb;
+        }
+        // A~cl = A~ + B~ K~ ; W = P~ A~cl ; Joseph form  P~ <- Q~_t + K~'(aR)K~ + A~cl' W.
+        // (The plain form Q~ + A~'W uses the open-loop A~ on one side: the antisymmetric
+        // rounding error of P~ -- which the transposed-operand trick turns into a sign flip --
+        // then grows ~3x per step on the quadrotor.  With A~cl on both sides it contracts.)
+        v4d Acl = __builtin_amdgcn_mfma_f64_16x16x4f64(Ba, Kb, Ab, 0, 0, 0);
+        v4d W = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KA; ++s) W = __builtin_amdgcn_mfma_f64_16x16x4f64(P[s], Acl[s], W, 0, 0, 0);
+        double RKb = 0.0;                             // (aR K~)[rg][col]
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            double rk = 0.0;
+#pragma unroll
+            for (int q = 0; q < M; ++q) rk -= Rr[i][q] * y[q];
+            RKb = (i == rg) ? rk : RKb;
+        }
+        if (rg >= M || col > N) RKb = 0.0;
+        v4d Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(Kb, RKb, Qt, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < KA; ++s) Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(Acl[s], W[s], Pn, 0, 0, 0);
+        P = Pn;
+    }
+    if (lane == 0) a.info[0] = bad_t;
+}
+
+template <int N, int M>
+__device__ __forceinline__ void riccati_backward_any(const RiccatiArgs& a, int lane, RiccatiLds<N, M>& S,
+                                                     double* qx) {
+    if constexpr (N <= 4 && M <= 2) {
+        riccati_backward_reg<N, M>(a, lane);
+    } else if constexpr (N + 1 <= 16 && M <= 4) {
+        if ((a.T + 1) * N <= kQxMax) riccati_backward_mfma<N, M>(a, lane, qx);
+        else riccati_backward<N, M>(a, lane, S);
+    } else {
+        riccati_backward<N, M>(a, lane, S);
+    }
 }
 
 template <int N, int M>
 __global__ __launch_bounds__(64) void riccati_kernel_t(RiccatiArgs a) {
     __shared__ RiccatiLds<N, M> S;
-    riccati_backward_any<N, M>(a, threadIdx.x, S);
+    __shared__ double qx[(N > 4 && N + 1 <= 16 && M <= 4) ? kQxMax : 1];
+    riccati_backward_any<N, M>(a, threadIdx.x, S, qx);
 }
 
 // ------------------------------------------------------------------ generic runtime sizes
@@ -853,7 +1035,8 @@ __global__ __launch_bounds__(64) void descent_kernel(ModelParams p, RiccatiArgs 
     __shared__ RiccatiLds<Model::NX, Model::NU> S;
     __shared__ RolloutLds<Model> S2;
     const int lane = threadIdx.x;
-    riccati_backward_any<Model::NX, Model::NU>(a, lane, S);
+    __shared__ double qx[(Model::NX > 4 && Model::NX + 1 <= 16 && Model::NU <= 4) ? kQxMax : 1];
+    riccati_backward_any<Model::NX, Model::NU>(a, lane, S, qx);
     // the gains were stored by this very wave: drain the stores, then re-read them
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
