@@ -47,6 +47,8 @@ struct SmoothTraits {
     static constexpr int PP = irs_reduce_pad(P);
     // last-arriver reduction: NGRP groups of P lanes each sum a strided subset of blocks
     static constexpr int NGRP = (P >= kBlock) ? 1 : kBlock / P;
+    // light = few accumulators AND a small functor: fits 1024-thread workgroups (128 VGPRs)
+    static constexpr bool LIGHT = PP <= 32 && d <= 7;
 };
 
 struct SmoothArgs {
@@ -60,6 +62,7 @@ struct SmoothArgs {
     unsigned long long sample_offset;
     unsigned int iter;
     int T, N, chunk, nblk, block;
+    int diag;          // tuning experiments only (IRS_DIAG): 1 = skip the fused solve
     int* counters;     // (T) arrival counters, zero between calls
     float* partial;    // (T, nblk, P)
     double* sums;      // (T, P) out
@@ -96,6 +99,19 @@ __device__ __forceinline__ void load_row(const float* __restrict__ ptr, float* o
 __device__ __forceinline__ void wave_sync() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+}
+
+// 1/sqrt(x) to ~1 ulp: hardware estimate + three Newton steps.  A correctly rounded f64
+// sqrt followed by a divide is ~70 dependent instructions on the critical path of EVERY
+// elimination step of the in-kernel solve.
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const double h = 0.5 * x * y;
+        y = fma(fma(-h, y, 0.5), y, y);
+    }
+    return y;
 }
 
 template <class Model, int MODE>
@@ -160,7 +176,7 @@ __device__ __forceinline__ void finalize_timestep(const ModelParams& p, const do
 #pragma unroll
             for (int i = 0; i < NZ; ++i) {
                 bool pos = g[i][i] > 0.0;
-                scl[i] = pos ? 1.0 / sqrt(g[i][i]) : 0.0;
+                scl[i] = pos ? fast_rsqrt(g[i][i]) : 0.0;
                 if (!pos && badr == 0) badr = i + 1;
             }
 #pragma unroll
@@ -172,8 +188,8 @@ __device__ __forceinline__ void finalize_timestep(const ModelParams& p, const do
                     if (badr == 0) badr = j + 1;
                     djj = 1.0;
                 }
-                lo[j][j] = sqrt(djj);
-                double il = 1.0 / lo[j][j];
+                const double il = fast_rsqrt(djj);
+                lo[j][j] = il;                       // the diagonal keeps 1/l_jj
 #pragma unroll
                 for (int i = j + 1; i < NZ; ++i) {
                     double s = g[i][j] * scl[i] * scl[j];
@@ -190,14 +206,14 @@ __device__ __forceinline__ void finalize_timestep(const ModelParams& p, const do
                     double s = h[i][k] * scl[i];
 #pragma unroll
                     for (int l = 0; l < i; ++l) s -= lo[i][l] * y[l];
-                    y[i] = s / lo[i][i];
+                    y[i] = s * lo[i][i];
                 }
 #pragma unroll
                 for (int i = NZ - 1; i >= 0; --i) {
                     double s = y[i];
 #pragma unroll
                     for (int l = i + 1; l < NZ; ++l) s -= lo[l][i] * y[l];
-                    y[i] = s / lo[i][i];
+                    y[i] = s * lo[i][i];
                 }
                 if (lane == 0) {
 #pragma unroll
@@ -224,46 +240,48 @@ __device__ __forceinline__ void finalize_timestep(const ModelParams& p, const do
         for (int q = lane; q < NZ * NZ; q += 64) L.G[q / NZ][q % NZ] *= L.sc[q / NZ] * L.sc[q % NZ];
         for (int q = lane; q < NZ * n; q += 64) L.H[q / n][q % n] *= L.sc[q / n];
         wave_sync();
-        // right-looking Cholesky, lower triangle in place
+        // Right-looking Cholesky of G' with the forward substitution folded in: the
+        // right-hand sides H' ride along as extra columns (after step j row j of H' holds
+        // y_j and the rows below have had L[r][j] y_j removed), then a column-oriented
+        // back substitution.  Every update is spread over the 64 lanes; nothing is
+        // unrolled (unrolling the solves hoists NZ^2/2 factor loads into registers and
+        // would cap the whole fused sample kernel at one wave per SIMD).
+        static_assert(NZ <= 32 && n <= 32, "lane split of the scaling step");
         for (int j = 0; j < NZ; ++j) {
             double djj = L.G[j][j];
             if (!(djj > 1e-14)) {
                 if (lane == 0 && L.bad == 0) L.bad = j + 1;
                 djj = 1.0;
             }
-            double l = sqrt(djj);
-            double il = 1.0 / l;
+            const double il = fast_rsqrt(djj);
             wave_sync();
-            if (lane == j) L.G[j][j] = l;
-            if (lane > j && lane < NZ) L.G[lane][j] *= il;
+            if (lane == j) L.G[j][j] = il;                            // the diagonal keeps 1/l_jj
+            if (lane > j && lane < NZ) L.G[lane][j] *= il;            // L[r][j]
+            if (lane >= 32 && lane < 32 + n) L.H[j][lane - 32] *= il; // y_j
             wave_sync();
-            // trailing update: element (r,c), j < c <= r < NZ
-            for (int q = lane; q < NZ * NZ; q += 64) {
+            for (int q = lane; q < NZ * NZ; q += 64) {                // (r,c), j < c <= r
                 int r = q / NZ, c = q % NZ;
                 if (c > j && r >= c) L.G[r][c] -= L.G[r][j] * L.G[c][j];
             }
+            for (int q = lane; q < NZ * n; q += 64) {                 // rows below j of H'
+                int r = q / n, k = q % n;
+                if (r > j) L.H[r][k] -= L.G[r][j] * L.H[j][k];
+            }
             wave_sync();
         }
-        // one lane per right-hand side: L y = h, L' w = y;  AB[k][Z0+i] = sc_i w_i
-        if (lane < n) {
-            double y[NZ];
-#pragma unroll
-            for (int i = 0; i < NZ; ++i) {
-                double s = L.H[i][lane];
-#pragma unroll
-                for (int k = 0; k < i; ++k) s -= L.G[i][k] * y[k];
-                y[i] = s / L.G[i][i];
+        // L' w = y, column oriented
+        for (int i = NZ - 1; i >= 0; --i) {
+            const double il = L.G[i][i];
+            wave_sync();
+            if (lane < n) L.H[i][lane] *= il;                         // w_i
+            wave_sync();
+            for (int q = lane; q < i * n; q += 64) {
+                int r = q / n, k = q % n;
+                L.H[r][k] -= L.G[i][r] * L.H[i][k];
             }
-#pragma unroll
-            for (int i = NZ - 1; i >= 0; --i) {
-                double s = y[i];
-#pragma unroll
-                for (int k = i + 1; k < NZ; ++k) s -= L.G[k][i] * y[k];
-                y[i] = s / L.G[i][i];
-            }
-#pragma unroll
-            for (int i = 0; i < NZ; ++i) L.AB[lane][Z0 + i] = y[i] * L.sc[i];
         }
+        wave_sync();
+        for (int q = lane; q < NZ * n; q += 64) L.AB[q % n][Z0 + q / n] = L.H[q / n][q % n] * L.sc[q / n];
         }  // NZ > 4
     }
     wave_sync();
@@ -288,7 +306,11 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
     constexpr int n = TR::n, m = TR::m, d = TR::d, NZ = TR::NZ, Z0 = TR::Z0, P = TR::P;
     constexpr int NW = BLOCK / 64;
     constexpr int P4 = (P + 3) / 4 * 4;     // row stride of the partial buffer (16-byte rows)
+    // matrix-core Gram path: zero-order, one 16-wide tile, too many statistics for registers
+    constexpr bool USE_MFMA = MODE == IRS_SMOOTH_ZERO_ORDER_AB && d <= 16 && n <= 16 && TR::PP > 64 &&
+                              BLOCK == kBlock;
     __shared__ float red[NW * TR::PP];
+    __shared__ float tile[USE_MFMA ? NW * 64 * 36 : 1];
     __shared__ double red64[TR::NGRP * P];
     __shared__ double tot[P];
     __shared__ FinalizeLds<Model, MODE> fin;
@@ -304,82 +326,152 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
     for (int j = 0; j < m; ++j) ub[j] = (float)a.u_trj[(size_t)t * m + j];
     if constexpr (MODE != IRS_SMOOTH_FIRST_ORDER) Model::template step<float>(a.p, xb, ub, f0);
 
-    float acc[TR::PP];
-#pragma unroll
-    for (int i = 0; i < TR::PP; ++i) acc[i] = 0.f;
-
-    // Sample loop.  U samples per lane are loaded together (independent loads in
-    // flight), then evaluated; out-of-range slots are clamped to a valid address and
-    // zeroed (a zero perturbation contributes exactly nothing to the zero-order sums).
     const int s_end = min(a.N, (blk + 1) * a.chunk);
-    constexpr int U = (TR::PP <= 64 && !RNG) ? 4 : 1;
-    for (int s0 = blk * a.chunk + tid; s0 < s_end; s0 += BLOCK * U) {
-        float zz[U][d];
-        bool valid[U];
+    if constexpr (USE_MFMA) {
+        // ---- matrix-core Gram accumulation (zero-order, d <= 16, many statistics) -------
+        // The P = d(d+1)/2 + d n statistics are the products Z'Z and Z'dF over the sample
+        // axis: exactly what v_mfma_f32_16x16x4_f32 contracts (k = 4 samples per issue),
+        // with the accumulators in 8 registers per WAVE instead of P per LANE.  Each lane
+        // evaluates one sample, stages [z | df] as a row of its wave's LDS tile (row stride
+        // 36 dwords: conflict-free 16-byte writes), and the wave re-reads the tile in
+        // operand layout (lane (i = l&15, k = l>>4) <- row 4 kk + k, column i); Z serves as
+        // both the A and the B operand of Z'Z.  f32 MFMA is an exact k-ordered fmaf chain.
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        constexpr int TS = 36;
+        const int lane = tid & 63, wave = tid >> 6, col = lane & 15, rg = lane >> 4;
+        float* my = tile + wave * 64 * TS;
+        v4f aG = {0.f, 0.f, 0.f, 0.f}, aH = {0.f, 0.f, 0.f, 0.f};
+        for (int s0 = blk * a.chunk + wave * 64; s0 < s_end; s0 += BLOCK) {
+            const int s = s0 + lane;
+            const bool valid = s < s_end;
+            float z[16], dfp[16];
 #pragma unroll
-        for (int uu = 0; uu < U; ++uu) {
-            const int s = s0 + uu * BLOCK;
-            valid[uu] = s < s_end;
+            for (int i = 0; i < 16; ++i) { z[i] = 0.f; dfp[i] = 0.f; }
             if constexpr (RNG) {
-                constexpr int j0 = Z0 / 4;
                 const unsigned long long gidx = a.sample_offset + (unsigned long long)s;
 #pragma unroll
-                for (int j = j0; j < (d + 3) / 4; ++j) {
+                for (int j = 0; j < (d + 3) / 4; ++j) {
                     float g[4];
                     philox_normal4(gidx, (unsigned)t, (unsigned)j, a.iter, a.seed, g);
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        if (4 * j + c < d) zz[uu][4 * j + c] = g[c] * a.std[4 * j + c];
+                        if (4 * j + c < d) z[4 * j + c] = g[c] * a.std[4 * j + c];
                 }
-#pragma unroll
-                for (int i = 0; i < Z0; ++i) zz[uu][i] = 0.f;
             } else {
-                const size_t row = (size_t)t * a.N + (valid[uu] ? s : s_end - 1);
-                if constexpr (Z0 == 0) load_row<n>(a.dx + row * n, zz[uu]);
-                else {
-#pragma unroll
-                    for (int i = 0; i < n; ++i) zz[uu][i] = 0.f;
-                }
-                load_row<m>(a.du + row * m, zz[uu] + n);
+                const size_t row = (size_t)t * a.N + (valid ? s : s_end - 1);
+                load_row<n>(a.dx + row * n, z);
+                load_row<m>(a.du + row * m, z + n);
             }
-        }
 #pragma unroll
-        for (int uu = 0; uu < U; ++uu) {
-            float z[d];
-#pragma unroll
-            for (int i = 0; i < d; ++i) z[i] = (U == 1 || valid[uu]) ? zz[uu][i] : 0.f;
+            for (int i = 0; i < d; ++i) z[i] = valid ? z[i] : 0.f;
             float xs[n], us[m], fx[n];
 #pragma unroll
             for (int i = 0; i < n; ++i) xs[i] = xb[i] + z[i];
 #pragma unroll
             for (int j = 0; j < m; ++j) us[j] = ub[j] + z[n + j];
+            Model::template step<float>(a.p, xs, us, fx);
+#pragma unroll
+            for (int k = 0; k < n; ++k) dfp[k] = fx[k] - f0[k];      // 0 for a zeroed slot
+            float4* rowp = reinterpret_cast<float4*>(my + lane * TS);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                rowp[q] = make_float4(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]);
+                rowp[4 + q] = make_float4(dfp[4 * q], dfp[4 * q + 1], dfp[4 * q + 2], dfp[4 * q + 3]);
+            }
+            wave_sync();
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const float av = my[(4 * kk + rg) * TS + col];
+                const float bv = my[(4 * kk + rg) * TS + 16 + col];
+                aG = __builtin_amdgcn_mfma_f32_16x16x4f32(av, av, aG, 0, 0, 0);
+                aH = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, aH, 0, 0, 0);
+            }
+            wave_sync();
+        }
+        // accumulator (row = 4 (l>>4) + reg, col = l&15) -> this wave's row of `red`, P-order
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * rg + r, j = col;
+            if (i < d && j < d && i <= j) red[wave * TR::PP + i * d - i * (i - 1) / 2 + (j - i)] = aG[r];
+            if (i < d && j < n) red[wave * TR::PP + TR::NG + i * n + j] = aH[r];
+        }
+    } else {
+        float acc[TR::PP];
+#pragma unroll
+        for (int i = 0; i < TR::PP; ++i) acc[i] = 0.f;
 
-            if constexpr (MODE == IRS_SMOOTH_FIRST_ORDER) {
-                float J[n * d];
-                model_jacobian<Model, float>(a.p, xs, us, fx, J);
-                const float w = (U == 1 || valid[uu]) ? 1.f : 0.f;
+        // Sample loop.  U samples per lane are loaded together (independent loads in
+        // flight), then evaluated; out-of-range slots are clamped to a valid address and
+        // zeroed (a zero perturbation contributes exactly nothing to the zero-order sums).
+        constexpr int U = (TR::LIGHT && !RNG) ? 4 : 1;
+        for (int s0 = blk * a.chunk + tid; s0 < s_end; s0 += BLOCK * U) {
+            float zz[U][d];
+            bool valid[U];
 #pragma unroll
-                for (int q = 0; q < n * d; ++q) acc[q] = fmaf(w, J[q], acc[q]);
-            } else {
-                Model::template step<float>(a.p, xs, us, fx);
-                float df[n];
+            for (int uu = 0; uu < U; ++uu) {
+                const int s = s0 + uu * BLOCK;
+                valid[uu] = s < s_end;
+                if constexpr (RNG) {
+                    constexpr int j0 = Z0 / 4;
+                    const unsigned long long gidx = a.sample_offset + (unsigned long long)s;
 #pragma unroll
-                for (int k = 0; k < n; ++k) df[k] = fx[k] - f0[k];
-                int q = 0;
+                    for (int j = j0; j < (d + 3) / 4; ++j) {
+                        float g[4];
+                        philox_normal4(gidx, (unsigned)t, (unsigned)j, a.iter, a.seed, g);
 #pragma unroll
-                for (int i = 0; i < NZ; ++i)
+                        for (int c = 0; c < 4; ++c)
+                            if (4 * j + c < d) zz[uu][4 * j + c] = g[c] * a.std[4 * j + c];
+                    }
 #pragma unroll
-                    for (int j = i; j < NZ; ++j) { acc[q] = fmaf(z[Z0 + i], z[Z0 + j], acc[q]); ++q; }
+                    for (int i = 0; i < Z0; ++i) zz[uu][i] = 0.f;
+                } else {
+                    const size_t row = (size_t)t * a.N + (valid[uu] ? s : s_end - 1);
+                    if constexpr (Z0 == 0) load_row<n>(a.dx + row * n, zz[uu]);
+                    else {
 #pragma unroll
-                for (int i = 0; i < NZ; ++i)
+                        for (int i = 0; i < n; ++i) zz[uu][i] = 0.f;
+                    }
+                    load_row<m>(a.du + row * m, zz[uu] + n);
+                }
+            }
 #pragma unroll
-                    for (int k = 0; k < n; ++k) { acc[q] = fmaf(z[Z0 + i], df[k], acc[q]); ++q; }
+            for (int uu = 0; uu < U; ++uu) {
+                float z[d];
+#pragma unroll
+                for (int i = 0; i < d; ++i) z[i] = (U == 1 || valid[uu]) ? zz[uu][i] : 0.f;
+                float xs[n], us[m], fx[n];
+#pragma unroll
+                for (int i = 0; i < n; ++i) xs[i] = xb[i] + z[i];
+#pragma unroll
+                for (int j = 0; j < m; ++j) us[j] = ub[j] + z[n + j];
+
+                if constexpr (MODE == IRS_SMOOTH_FIRST_ORDER) {
+                    float J[n * d];
+                    model_jacobian<Model, float>(a.p, xs, us, fx, J);
+                    const float w = (U == 1 || valid[uu]) ? 1.f : 0.f;
+#pragma unroll
+                    for (int q = 0; q < n * d; ++q) acc[q] = fmaf(w, J[q], acc[q]);
+                } else {
+                    Model::template step<float>(a.p, xs, us, fx);
+                    float df[n];
+#pragma unroll
+                    for (int k = 0; k < n; ++k) df[k] = fx[k] - f0[k];
+                    int q = 0;
+#pragma unroll
+                    for (int i = 0; i < NZ; ++i)
+#pragma unroll
+                        for (int j = i; j < NZ; ++j) { acc[q] = fmaf(z[Z0 + i], z[Z0 + j], acc[q]); ++q; }
+#pragma unroll
+                    for (int i = 0; i < NZ; ++i)
+#pragma unroll
+                        for (int k = 0; k < n; ++k) { acc[q] = fmaf(z[Z0 + i], df[k], acc[q]); ++q; }
+                }
             }
         }
-    }
 
-    // ---- workgroup reduction: registers -> shuffles -> LDS -------------------------
-    block_reduce_lds<P, NW>(acc, red);
+        // ---- workgroup reduction: registers -> shuffles -> LDS ---------------------
+        block_reduce_lds<P, NW>(acc, red);
+    }
     __syncthreads();
 
     const int nblk = a.nblk;
@@ -457,7 +549,7 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
     __syncthreads();
     for (int q = tid; q < P; q += BLOCK) a.sums[(size_t)t * P + q] = tot[q];
     if constexpr (FUSE) {
-        if (tid < 64)
+        if (tid < 64 && a.diag != 1)
             finalize_timestep<Model, MODE>(a.p, a.x_trj, a.u_trj, tot, a.n_total, t, tid, fin, a.At, a.Bt,
                                            a.ct, a.info);
     }
@@ -534,7 +626,7 @@ int tune_min_wg() { static int v = env_int("IRS_MIN_WG", 256); return v; }      
 constexpr int kBigBlock = 1024;
 
 // Chooses the launch geometry for (T, N).  `light` = the kernel's accumulators fit a
-// 1024-thread workgroup (PP <= 64).  Measured on MI355X (profiles/): every extra
+// 1024-thread workgroup (SmoothTraits::LIGHT).  Measured on MI355X (profiles/): every extra
 // workgroup costs more (its hand-off: write-through stores + ticket) than it gains in
 // streaming parallelism once the CUs are covered, so grids stay SMALL:
 //  * light, samples supplied, N <= tune_single_max(): ONE 1024-thread workgroup per
@@ -574,6 +666,26 @@ template <class Model, int MODE>
 int sums_len_t() { return SmoothTraits<Model, MODE>::P; }
 
 template <class Model>
+bool light_m(int mode) {
+    switch (mode) {
+        case IRS_SMOOTH_ZERO_ORDER_AB: return SmoothTraits<Model, IRS_SMOOTH_ZERO_ORDER_AB>::LIGHT;
+        case IRS_SMOOTH_FIRST_ORDER: return SmoothTraits<Model, IRS_SMOOTH_FIRST_ORDER>::LIGHT;
+        case IRS_SMOOTH_ZERO_ORDER_B: return SmoothTraits<Model, IRS_SMOOTH_ZERO_ORDER_B>::LIGHT;
+    }
+    return false;
+}
+
+bool is_light(int model, int mode) {
+    switch (model) {
+        case IRS_MODEL_PENDULUM: return light_m<PendulumModel>(mode);
+        case IRS_MODEL_QUADROTOR: return light_m<QuadrotorModel>(mode);
+        case IRS_MODEL_BICYCLE: return light_m<BicycleModel>(mode);
+        case IRS_MODEL_THREE_CART: return light_m<ThreeCartModel>(mode);
+    }
+    return false;
+}
+
+template <class Model>
 int sums_len_m(int mode) {
     switch (mode) {
         case IRS_SMOOTH_ZERO_ORDER_AB: return sums_len_t<Model, IRS_SMOOTH_ZERO_ORDER_AB>();
@@ -597,7 +709,7 @@ void launch_smooth_b(const SmoothArgs& a, bool rng, bool fuse, hipStream_t st) {
 
 template <class Model, int MODE>
 void launch_smooth_m(const SmoothArgs& a, bool rng, bool fuse, hipStream_t st) {
-    if constexpr (SmoothTraits<Model, MODE>::PP <= 64) {
+    if constexpr (SmoothTraits<Model, MODE>::LIGHT) {
         if (a.block == kBigBlock) { launch_smooth_b<Model, MODE, kBigBlock>(a, rng, fuse, st); return; }
     }
     launch_smooth_b<Model, MODE, kBlock>(a, rng, fuse, st);
@@ -652,7 +764,8 @@ int smooth_common(int model, const double* params, int n_params, int mode, int T
     }
     a.x_trj = x_trj; a.u_trj = u_trj;
     a.T = T; a.N = N;
-    plan_grid(T, N, irs_reduce_pad(irs_sums_len(model, mode)) <= 64, rng, &a.chunk, &a.nblk, &a.block);
+    plan_grid(T, N, is_light(model, mode), rng, &a.chunk, &a.nblk, &a.block);
+    { static int dg = getenv("IRS_DIAG") ? atoi(getenv("IRS_DIAG")) : 0; a.diag = dg; }
     a.counters = static_cast<int*>(workspace);
     a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + kCounterBytes);
     a.sums = sums;
@@ -704,7 +817,7 @@ size_t irs_smooth_workspace_bytes(int model, int mode, int T, int N) {
     int P = irs_sums_len(model, mode);
     if (P <= 0 || T <= 0 || N <= 0) return 0;
     int chunk, nblk, block;
-    plan_grid(T, N, irs_reduce_pad(P) <= 64, /*rng=*/true, &chunk, &nblk, &block);   // the larger grid
+    plan_grid(T, N, is_light(model, mode), /*rng=*/true, &chunk, &nblk, &block);   // the larger grid
     return kCounterBytes + (size_t)T * nblk * ((P + 3) / 4 * 4) * sizeof(float);
 }
 

@@ -15,8 +15,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from irs_mpc_amd import PendulumDynamics, QuadrotorDynamics, device as dev, _lib  # noqa: E402
 
 model, mode_s, T, N = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
-rng_mode = len(sys.argv) > 5 and sys.argv[5] == "rng"
-sysd = PendulumDynamics(0.05) if model == "pendulum" else QuadrotorDynamics(0.05)
+rng_mode = len(sys.argv) > 5 and "rng" in sys.argv[5:]
+fuse = "nofuse" not in sys.argv[5:]
+from irs_mpc_amd import BicycleDynamics, ThreeCartDynamics  # noqa: E402
+sysd = {"pendulum": PendulumDynamics(0.05), "quadrotor": QuadrotorDynamics(0.05), "bicycle": BicycleDynamics(0.1),
+        "three_cart": ThreeCartDynamics(0.05)}[model]
 mode = {"zero": _lib.SMOOTH_ZERO_ORDER_AB, "first": _lib.SMOOTH_FIRST_ORDER, "zeroB": _lib.SMOOTH_ZERO_ORDER_B}[mode_s]
 dm = sysd.dm()
 n, m = dm.n, dm.m
@@ -27,12 +30,12 @@ Q, R = dev.to_dev(np.eye(n)), dev.to_dev(np.eye(m))
 xd = dev.to_dev(np.zeros((T + 1, n)))
 x_trj, _ = dm.rollout_cost(dev.to_dev(np.zeros(n)), u_trj, Q, R, xd)
 if rng_mode:
-    plan = dev.SmoothPlan(dm, mode, x_trj, u_trj, rng=dict(N=N, std_x=[std] * n, std_u=[std] * m, seed=1, iter=1))
+    plan = dev.SmoothPlan(dm, mode, x_trj, u_trj, rng=dict(N=N, std_x=[std] * n, std_u=[std] * m, seed=1, iter=1), fuse=fuse)
 else:
     g = torch.Generator(device="cuda").manual_seed(0)
     dx = std * torch.randn((T, N, n), generator=g, device="cuda", dtype=torch.float32)
     du = std * torch.randn((T, N, m), generator=g, device="cuda", dtype=torch.float32)
-    plan = dev.SmoothPlan(dm, mode, x_trj, u_trj, dx=dx, du=du)
+    plan = dev.SmoothPlan(dm, mode, x_trj, u_trj, dx=dx, du=du, fuse=fuse)
 st = torch.cuda.current_stream().cuda_stream
 for _ in range(10):
     plan.run(st)
@@ -53,5 +56,5 @@ torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / reps
 byt = 4 * ((n + m) if mode != _lib.SMOOTH_ZERO_ORDER_B else m) * N * T
 print("%s %s T=%d N=%d %s env[SPT=%s SINGLE=%s MAXWG=%s]: event med %.2f us min %.2f | wall %.2f us | %.0f GB/s (wall) %.3g samples/s"
-      % (model, mode_s, T, N, "rng" if rng_mode else "supplied", os.environ.get("IRS_SPT"), os.environ.get("IRS_SINGLE_MAX"),
+      % (model, mode_s, T, N, ("rng" if rng_mode else "supplied") + ("" if fuse else " NOFUSE"), os.environ.get("IRS_SPT"), os.environ.get("IRS_SINGLE_MAX"),
          os.environ.get("IRS_MAX_WG"), ts[len(ts) // 2] * 1e3, ts[0] * 1e3, wall * 1e6, byt / wall / 1e9, N * T / wall))
