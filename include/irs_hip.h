@@ -208,6 +208,25 @@ int irs_tvlqr_descent(int model, const double *params, int n_params, int T,
                       const double *xd_trj, const double *x0, double *K, double *k,
                       double *x_new, double *u_new, double *cost, int *info, void *stream);
 
+/* IrsLqr.local_descent (irs_lqr/irs_lqr.py:148-186) with ACTIVE absolute box bounds
+ * (solve_tvlqr's x_bound_abs / u_bound_abs, irs_lqr/tv_lqr.py:112-123): T tail QPs, each
+ * re-solved from the realised state, first control applied to the true dynamics.  The QPs
+ * (OSQP in the reference) are solved by ADMM on the box around one shared Riccati
+ * factorisation, warm started from tail to tail.  xlo,xhi (n), ulo,uhi (m) DEV f64, +-inf =
+ * unbounded, applied to x_1..x_T and u_0..u_{T-1}.  rho > 0 ADMM penalty, 0 < relax < 2
+ * over-relaxation, stop at max(primal, dual residual) < eps or max_iter.
+ * info (3) DEV int32: [0] t+1 of a non-PD Hessian (0 ok), [1] most ADMM iterations any tail
+ * needed, [2] number of tails that stopped at max_iter.  One launch; the factorisation lives
+ * in LDS, so T is limited (irs_tvlqr_box_lds_bytes(model,T) <= ~160 KB).                 */
+int irs_tvlqr_box_descent(int model, const double *params, int n_params, int T,
+                          const double *At, const double *Bt, const double *ct,
+                          const double *Q, const double *Qd, const double *R, double alpha_R,
+                          const double *xd_trj, const double *x0,
+                          const double *xlo, const double *xhi, const double *ulo, const double *uhi,
+                          double rho, double relax, int max_iter, double eps,
+                          double *x_new, double *u_new, int *info, void *stream);
+size_t irs_tvlqr_box_lds_bytes(int model, int T);
+
 /* ---- Cross-entropy-method baseline (irs_lqr/cem.py:151-184) -------------------- */
 
 /* Steps 1-2 of CrossEntropyMethod.local_descent (cem.py:163-168): roll out each of the

@@ -152,6 +152,30 @@ class DeviceModel:
               "irs_tvlqr_descent")
         return o
 
+    # ---- box-constrained descent ----------------------------------------------
+    BOX_LDS_LIMIT = 160 * 1024 - 512
+
+    def box_descent_supported(self, T):
+        return 0 < self.lib.irs_tvlqr_box_lds_bytes(self.model_id, int(T)) <= self.BOX_LDS_LIMIT
+
+    def tvlqr_box_descent(self, At, Bt, ct, Q, Qd, R, xd_trj, x0, xlo, xhi, ulo, uhi, alpha_R=0.5,
+                          rho=10.0, relax=1.6, max_iter=5000, eps=1e-8):
+        """local_descent with active abs bounds (T warm-started tail QPs by ADMM around one
+        Riccati factorisation).  Returns dict(x_new, u_new, info[3])."""
+        T = At.shape[0]
+        dev = At.device
+        o = dict(x_new=torch.empty((T + 1, self.n), dtype=F64, device=dev),
+                 u_new=torch.empty((T, self.m), dtype=F64, device=dev),
+                 info=torch.empty((3,), dtype=torch.int32, device=dev))
+        check(self.lib.irs_tvlqr_box_descent(self.model_id, self._p, self._np, T, _ptr(At, F64), _ptr(Bt, F64),
+                                             _ptr(ct, F64), _ptr(Q, F64), _ptr(Qd, F64), _ptr(R, F64),
+                                             float(alpha_R), _ptr(xd_trj, F64), _ptr(x0, F64), _ptr(xlo, F64),
+                                             _ptr(xhi, F64), _ptr(ulo, F64), _ptr(uhi, F64), float(rho),
+                                             float(relax), int(max_iter), float(eps), _ptr(o["x_new"], F64),
+                                             _ptr(o["u_new"], F64), o["info"].data_ptr(), _stream()),
+              "irs_tvlqr_box_descent")
+        return o
+
     # ---- CEM baseline -------------------------------------------------------
     def cem_rollout_costs(self, u_cand, x0, Q, R, xd_trj):
         """costs (B) of the B candidate sequences u_cand (B,T,m): rollout + evaluate_cost each."""

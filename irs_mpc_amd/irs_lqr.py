@@ -134,12 +134,50 @@ class IrsLqr:
 
     def _local_descent_dev(self, x_trj, u_trj):
         At, Bt, ct = self._get_TV_matrices_dev(x_trj, u_trj)
+        box = self._box_bounds()
+        if box is not None and self._dm.box_descent_supported(self.T):
+            # genuine bounds (tv_lqr.py:112-123): T warm-started tail QPs, one launch
+            o = self._dm.tvlqr_box_descent(At, Bt, ct, self._Q, self._Qd, self._R, self._xd,
+                                           x_trj[0].contiguous(), *box, alpha_R=0.5,
+                                           rho=getattr(self.params, "qp_rho", 10.0),
+                                           max_iter=getattr(self.params, "qp_max_iter", 5000),
+                                           eps=getattr(self.params, "qp_eps", 1e-8))
+            cost = dev.evaluate_cost(o["x_new"], o["u_new"], self._Q, self._R, self._xd)
+            self._last = dict(At=At, Bt=Bt, ct=ct, K=None, k=None, info=o["info"][:1], box_info=o["info"])
+            self._box_used = True
+            return o["x_new"], o["u_new"], cost
         # T MPC re-solves of the tail QP == one Riccati pass + closed-loop rollout
         # while the box bounds are inactive (checked in iterate()); one launch.
+        self._box_used = False
         o = self._dm.tvlqr_descent(At, Bt, ct, self._Q, self._Qd, self._R, self._xd, x_trj[0].contiguous(),
                                    alpha_R=0.5)
         self._last = dict(At=At, Bt=Bt, ct=ct, K=o["K"], k=o["k"], info=o["info"])
         return o["x_new"], o["u_new"], o["cost"]
+
+    # |bound| >= this is how the reference's scripts spell "no bound" (1e4, 1e5)
+    NO_BOUND = 1e3
+
+    def _box_bounds(self):
+        """(xlo, xhi, ulo, uhi) device vectors with +-inf for absent / 'no bound' entries, or
+        None when nothing is genuinely bounded."""
+        if getattr(self, "_box_cache", None) is not None:
+            return self._box_cache if self._box_cache != () else None
+
+        def vec(b, dim):
+            lo, hi = np.full(dim, -np.inf), np.full(dim, np.inf)
+            if b is not None:
+                bl, bh = np.asarray(b[0], float), np.asarray(b[1], float)
+                lo = np.where(np.abs(bl) < self.NO_BOUND, bl, -np.inf)
+                hi = np.where(np.abs(bh) < self.NO_BOUND, bh, np.inf)
+            return lo, hi
+
+        xlo, xhi = vec(self.xbound, self.dim_x)
+        ulo, uhi = vec(self.ubound, self.dim_u)
+        if not (np.isfinite(xlo).any() or np.isfinite(xhi).any() or np.isfinite(ulo).any() or np.isfinite(uhi).any()):
+            self._box_cache = ()
+            return None
+        self._box_cache = tuple(dev.to_dev(a) for a in (xlo, xhi, ulo, uhi))
+        return self._box_cache
 
     def _check_smooth_info(self):
         info = getattr(self, "_smooth_info", None)
@@ -149,6 +187,12 @@ class IrsLqr:
                              "(Gram matrix not positive definite; need more samples or a non-zero std)" % t)
 
     def _check_bounds_inactive(self, x_new, u_new):
+        if getattr(self, "_box_used", False):
+            # the bounded QPs were solved; like OSQP hitting its iteration limit
+            # (tv_lqr.py:139-140), an unconverged tail problem is a failure
+            if int(self._last["box_info"][2].item()) != 0:
+                raise ValueError("TV_LQR failed. Optimization problem is not solved.")
+            return
         tol = 1e-9
         if self.xbound is not None:
             lo, hi = np.asarray(self.xbound[0], float), np.asarray(self.xbound[1], float)

@@ -613,3 +613,158 @@ def zero_order_from_sums(system, x_trj, u_trj, sums):
         At[t], Bt[t] = AB[:, :n], AB[:, n:]
         ct[t] = system.dynamics(x_trj[t], u_trj[t]) - At[t].dot(x_trj[t]) - Bt[t].dot(u_trj[t])
     return At, Bt, ct
+
+
+# --------------------------------------------------------------------------
+# Box-constrained TV-LQR (irs_lqr/tv_lqr.py:112-123 with ACTIVE bounds) -- the QP the
+# reference hands to OSQP, solved here by ADMM on the box with the equality-
+# constrained (LQR) sub-problem solved exactly by a Riccati sweep:
+#     min f(z) + I_box(w)  s.t. z = w,   f = quadratic cost + dynamics,
+#     z <- argmin f(z) + rho/2 |z - w + y|^2 ; w <- clip(z + y) ; y <- y + z - w.
+# Only BOUNDED components carry a rho term.  The Riccati matrices depend on
+# (A,B,Q,R,rho) only: one factorisation serves every ADMM iteration AND every one of
+# the T MPC tail re-solves of IrsLqr.local_descent (irs_lqr.py:169-184).
+# OSQP's default accuracy is 1e-3 (Drake OsqpSolver), so the reference's own curves
+# carry that much solver noise; this restatement converges to ~1e-9.
+# --------------------------------------------------------------------------
+def _box_masks(lo, hi):
+    lo, hi = np.asarray(lo, float), np.asarray(hi, float)
+    return lo, hi, (np.isfinite(lo) | np.isfinite(hi)).astype(float)
+
+
+def tvlqr_box_factor(At, Bt, ct, Q, Qd, R, xlo, xhi, ulo, uhi, rho, alpha_R=0.5):
+    """Backward sweep with Q^ = Q + rho/2 Mx, R^ = alpha R + rho/2 Mu (M = bounded mask)."""
+    T, n, m = At.shape[0], Q.shape[0], R.shape[0]
+    _, _, mx = _box_masks(xlo, xhi)
+    _, _, mu = _box_masks(ulo, uhi)
+    Qh, Qdh = Q + 0.5 * rho * np.diag(mx), Qd + 0.5 * rho * np.diag(mx)
+    Rh = alpha_R * R + 0.5 * rho * np.diag(mu)
+    F = dict(K=np.zeros((T, m, n)), Acl=np.zeros((T, n, n)), Hinv=np.zeros((T, m, m)),
+             Minv=np.zeros((T, m, n)), d=np.zeros((T, n)), mx=mx, mu=mu, rho=rho)
+    P = Qdh.copy()
+    for t in range(T - 1, -1, -1):
+        A, B = At[t], Bt[t]
+        H = Rh + B.T @ P @ B
+        Hinv = np.linalg.inv(H)
+        F["Hinv"][t] = Hinv
+        F["Minv"][t] = Hinv @ B.T
+        F["K"][t] = -Hinv @ B.T @ P @ A
+        F["Acl"][t] = A + B @ F["K"][t]
+        F["d"][t] = P @ ct[t]
+        P = Qh + A.T @ P @ F["Acl"][t]
+        P = 0.5 * (P + P.T)
+    return F
+
+
+def tvlqr_box_solve(F, At, Bt, ct, Q, Qd, xd, x_start, t0, xlo, xhi, ulo, uhi, state=None,
+                    max_iter=2000, eps=1e-9):
+    """ADMM for the tail problem t0..T from the fixed state x_start.  `state` = (wx, yx,
+    wu, yu) warm start (arrays over the FULL horizon).  Returns x (T+1,n), u (T,m) (rows
+    < t0 untouched/zero), state, iterations."""
+    T, n = At.shape[0], Q.shape[0]
+    m = Bt.shape[2]
+    rho, mx, mu = F["rho"], F["mx"], F["mu"]
+    xlo, xhi = np.asarray(xlo, float), np.asarray(xhi, float)
+    ulo, uhi = np.asarray(ulo, float), np.asarray(uhi, float)
+    if state is None:
+        state = (np.zeros((T + 1, n)), np.zeros((T + 1, n)), np.zeros((T, m)), np.zeros((T, m)))
+    wx, yx, wu, yu = state
+    zx, zu, k = np.zeros((T + 1, n)), np.zeros((T, m)), np.zeros((T, m))
+    it = 0
+    for it in range(1, max_iter + 1):
+        # backward affine sweep
+        p = -(Qd @ xd[T] + 0.5 * rho * mx * (wx[T] - yx[T]))
+        for t in range(T - 1, t0 - 1, -1):
+            g = F["d"][t] + p
+            s = -0.5 * rho * mu * (wu[t] - yu[t])
+            k[t] = -(F["Minv"][t] @ g + F["Hinv"][t] @ s)
+            q = -(Q @ xd[t] + 0.5 * rho * mx * (wx[t] - yx[t]))
+            p = q + F["Acl"][t].T @ g + F["K"][t].T @ s
+        # forward sweep on the linear model
+        zx[t0] = x_start
+        for t in range(t0, T):
+            zu[t] = F["K"][t] @ zx[t] + k[t]
+            zx[t + 1] = At[t] @ zx[t] + Bt[t] @ zu[t] + ct[t]
+        # box projection + dual update (x_t0 is fixed, not a variable)
+        wxn = np.clip(zx[t0 + 1:] + yx[t0 + 1:], xlo, xhi)
+        wun = np.clip(zu[t0:] + yu[t0:], ulo, uhi)
+        rp = max(np.abs(mx * (zx[t0 + 1:] - wxn)).max(), np.abs(mu * (zu[t0:] - wun)).max())
+        rd = rho * max(np.abs(mx * (wxn - wx[t0 + 1:])).max(), np.abs(mu * (wun - wu[t0:])).max())
+        yx[t0 + 1:] += mx * (zx[t0 + 1:] - wxn)
+        yu[t0:] += mu * (zu[t0:] - wun)
+        wx[t0 + 1:], wu[t0:] = wxn, wun
+        if max(rp, rd) < eps:
+            break
+    return zx, zu, (wx, yx, wu, yu), it
+
+
+def local_descent_box(system, At, Bt, ct, Q, Qd, R, x0, xd_trj, xlo, xhi, ulo, uhi, rho=1.0,
+                      max_iter=2000, eps=1e-9):
+    """irs_lqr/irs_lqr.py:148-186 with active abs bounds: T tail re-solves (warm started),
+    first control applied to the TRUE dynamics."""
+    T = At.shape[0]
+    n, m = system.dim_x, system.dim_u
+    F = tvlqr_box_factor(At, Bt, ct, Q, Qd, R, xlo, xhi, ulo, uhi, rho)
+    x_new, u_new = np.zeros((T + 1, n)), np.zeros((T, m))
+    x_new[0] = x0
+    state, iters = None, []
+    for t in range(T):
+        zx, zu, state, it = tvlqr_box_solve(F, At, Bt, ct, Q, Qd, xd_trj, x_new[t], t, xlo, xhi, ulo, uhi,
+                                            state, max_iter, eps)
+        iters.append(it)
+        u_new[t] = np.clip(zu[t], ulo, uhi)
+        x_new[t + 1] = system.dynamics(x_new[t], u_new[t])
+    return x_new, u_new, iters
+
+
+def qp_box_kkt_residuals(At, Bt, ct, Q, Qd, R, x0, xd, xlo, xhi, ulo, uhi, x, u, alpha_R=0.5, tol=1e-6):
+    """Optimality certificate of (x,u) for the box-constrained QP of tv_lqr.py:69-137,
+    independent of how it was solved.  With z = (x_1..x_T, u_0..u_{T-1}) (x_0 is fixed),
+    objective 1/2 z'Hz + g'z, dynamics E z = b and box l <= z <= h, KKT reads
+        H z + g + E'nu + mu = 0,  mu_i >= 0 on an active upper bound, <= 0 on an active
+        lower bound, = 0 elsewhere.
+    (nu, mu_active) are recovered by least squares; returns (dynamics residual, bound
+    violation, stationarity residual, worst multiplier sign violation) -- all ~0 at the
+    solution."""
+    T, n = At.shape[0], Q.shape[0]
+    m = R.shape[0]
+    xlo, xhi = np.broadcast_to(np.asarray(xlo, float), (n,)), np.broadcast_to(np.asarray(xhi, float), (n,))
+    ulo, uhi = np.broadcast_to(np.asarray(ulo, float), (m,)), np.broadcast_to(np.asarray(uhi, float), (m,))
+    nz = T * n + T * m
+    ix = lambda t: slice((t - 1) * n, t * n)                 # x_t, t = 1..T
+    iu = lambda t: slice(T * n + t * m, T * n + (t + 1) * m)
+    H, g = np.zeros((nz, nz)), np.zeros(nz)
+    for t in range(1, T + 1):
+        W = Qd if t == T else Q
+        H[ix(t), ix(t)] = 2.0 * W
+        g[ix(t)] = -2.0 * W @ xd[t]
+    for t in range(T):
+        H[iu(t), iu(t)] = 2.0 * alpha_R * R
+    E, b = np.zeros((T * n, nz)), np.zeros(T * n)
+    for t in range(T):                                       # A x_t + B u_t - x_{t+1} = -c_t
+        r = slice(t * n, (t + 1) * n)
+        if t > 0:
+            E[r, ix(t)] = At[t]
+        else:
+            b[r] -= At[0] @ x0
+        E[r, iu(t)] = Bt[t]
+        E[r, ix(t + 1)] = -np.eye(n)
+        b[r] -= ct[t]
+    z = np.concatenate([x[1:].ravel(), u.ravel()])
+    lo = np.concatenate([np.tile(xlo, T), np.tile(ulo, T)])
+    hi = np.concatenate([np.tile(xhi, T), np.tile(uhi, T)])
+    r_dyn = np.abs(E @ z - b).max()
+    r_box = max(0.0, (lo - z).max(), (z - hi).max())
+    at_hi, at_lo = z >= hi - tol, z <= lo + tol
+    act = np.where(at_hi | at_lo)[0]
+    Msys = np.hstack([E.T, np.eye(nz)[:, act]])
+    sol = np.linalg.lstsq(Msys, -(H @ z + g), rcond=None)[0]
+    r_stat = np.abs(Msys @ sol + H @ z + g).max()
+    mu = sol[T * n:]
+    sign_bad = 0.0
+    for j, i in enumerate(act):
+        if at_hi[i] and not at_lo[i]:
+            sign_bad = max(sign_bad, -mu[j])
+        elif at_lo[i] and not at_hi[i]:
+            sign_bad = max(sign_bad, mu[j])
+    return r_dyn, r_box, r_stat, sign_bad

@@ -251,7 +251,9 @@ def main():
     for src, dst in [("examples/pendulum/analysis/pendulum_exact.csv", "pendulum_exact.csv"),
                      ("examples/quadrotor/analysis/quadrotor_exact.csv", "quadrotor_exact.csv"),
                      ("examples/pendulum/analysis/pendulum_zero_order.csv", "pendulum_zero_order.csv"),
-                     ("examples/pendulum/analysis/pendulum_first_order.csv", "pendulum_first_order.csv")]:
+                     ("examples/pendulum/analysis/pendulum_first_order.csv", "pendulum_first_order.csv"),
+                     ("examples/bicycle/analysis/bicycle_easy_exact.csv", "bicycle_easy_exact.csv"),
+                     ("examples/bicycle/analysis/bicycle_hard_exact.csv", "bicycle_hard_exact.csv")]:
         shutil.copyfile(os.path.join(REF, src), os.path.join(HERE, dst))
         print("copied", dst)
 

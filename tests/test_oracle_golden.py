@@ -135,6 +135,65 @@ def test_three_cart_fixture(golden_dir):
         assert np.array_equal(s.dynamics(f["X"][i], f["U"][i]), f["Xn_scalar"][i])
 
 
+# ---- box-constrained TV-LQR (tv_lqr.py:112-123 with active bounds) -------------------
+def bike_problem(T):
+    Q, Qd, R = np.diag([5, 5, 3, 0.1, 0.1]), np.diag([50., 50, 30, 1, 1]), np.diag([1, 0.1])
+    x0 = np.zeros(5)
+    xd = np.tile(np.array([3.0, 1.0, np.pi / 2, 0, 0]), (T + 1, 1))
+    u0 = np.tile(np.array([0.1, 0.0]), (T, 1))
+    return Q, Qd, R, x0, xd, u0
+
+
+def test_box_qp_solution_satisfies_kkt():
+    """The ADMM/Riccati QP solution is certified by the QP's own KKT conditions
+    (multipliers recovered by least squares), with state AND input bounds active."""
+    T = 25
+    s = orc.BicycleOracle(0.1)
+    Q, Qd, R, x0, xd, u0 = bike_problem(T)
+    xlo = np.array([-np.inf] * 4 + [-0.3])
+    ulo = np.array([-2.0, -np.inf])
+    x = orc.rollout(s, x0, u0)
+    At, Bt, ct = orc.exact_TV(s, x, u0)
+    F = orc.tvlqr_box_factor(At, Bt, ct, Q, Qd, R, xlo, -xlo, ulo, -ulo, 10.0)
+    zx, zu, _, it = orc.tvlqr_box_solve(F, At, Bt, ct, Q, Qd, xd, x0, 0, xlo, -xlo, ulo, -ulo, None, 20000, 1e-10)
+    assert it < 20000
+    assert (np.abs(zx[:, 4]) > 0.3 - 1e-6).sum() > 5 and (np.abs(zu[:, 0]) > 2 - 1e-6).sum() > 2
+    r_dyn, r_box, r_stat, sign_bad = orc.qp_box_kkt_residuals(At, Bt, ct, Q, Qd, R, x0, xd, xlo, -xlo, ulo, -ulo, zx, zu)
+    assert r_dyn < 1e-10 and r_box < 1e-8 and r_stat < 1e-7 and sign_bad < 1e-7
+    # with every bound infinite the same code returns the equality-constrained QP solution
+    inf5, inf2 = np.full(5, np.inf), np.full(2, np.inf)
+    F2 = orc.tvlqr_box_factor(At, Bt, ct, Q, Qd, R, -inf5, inf5, -inf2, inf2, 10.0)
+    zx2, zu2, _, it2 = orc.tvlqr_box_solve(F2, At, Bt, ct, Q, Qd, xd, x0, 0, -inf5, inf5, -inf2, inf2)
+    xq, uq = orc.solve_tvlqr_qp(At, Bt, ct, Q, Qd, R, x0, xd)
+    assert it2 == 1
+    np.testing.assert_allclose(zu2, uq, rtol=1e-9, atol=1e-10)
+
+
+def test_bicycle_exact_csv_first_descent(golden_dir):
+    """examples/bicycle/bicycle_exact.py (steer bound +-pi/4 ACTIVE) vs the first entries of
+    examples/bicycle/analysis/bicycle_easy_exact.csv.  The reference's curve carries OSQP's
+    default 1e-3 accuracy on each of the 100 tail QPs of a descent, so it is matched to ~1 %
+    on the first descent only (the iLQR map amplifies solver noise afterwards)."""
+    gold = np.loadtxt(os.path.join(golden_dir, "bicycle_easy_exact.csv"))
+    T = 100
+    s = orc.BicycleOracle(0.1)
+    Q, Qd, R, x0, xd, u0 = bike_problem(T)
+    xlo = np.array([-np.inf] * 4 + [-np.pi / 4])
+    inf2 = np.full(2, np.inf)
+    x = orc.rollout(s, x0, u0)
+    assert orc.evaluate_cost(x, u0, xd, Q, R) == pytest.approx(gold[0], rel=1e-13)
+    At, Bt, ct = orc.exact_TV(s, x, u0)
+    xn, un, iters = orc.local_descent_box(s, At, Bt, ct, Q, Qd, R, x0, xd, xlo, -xlo, -inf2, inf2, rho=10.0,
+                                          max_iter=5000, eps=1e-8)
+    assert max(iters) < 5000
+    c1 = orc.evaluate_cost(xn, un, xd, Q, R)
+    assert abs(c1 - gold[1]) / gold[1] < 0.012
+    assert np.abs(xn[:, 4]).max() < np.pi / 4 + 1e-3          # the bound shapes the plan
+    # without the bound the Riccati descent leaves the feasible set by a wide margin
+    xr, ur, _, _ = orc.local_descent(s, At, Bt, ct, Q, Qd, R, x0, xd)
+    assert np.abs(xr[:, 4]).max() > np.pi / 4 + 0.1
+
+
 # ---- Jacobians: exact derivative vs central differences of the pinned dynamics
 @pytest.mark.parametrize("sysname", ["pendulum", "quadrotor"])
 def test_jacobian_vs_finite_difference(sysname):
