@@ -688,3 +688,19 @@ def test_cem_iterate_reduces_cost(amd):
     assert len(cem.cost_lst) == 7
     assert all(b < a for a, b in zip(cem.cost_lst, cem.cost_lst[1:]))      # monotone descent here
     assert cem.cost_lst[-1] < 0.92 * cem.cost_lst[0]
+
+
+# ---------------------------------------------------------------- example scripts
+@pytest.mark.parametrize("argv", [["pendulum", "zero_order", "--iters", "2", "--T", "60", "--quiet"],
+                                  ["quadrotor", "first_order", "--iters", "1", "--T", "30", "--N", "200", "--quiet",
+                                   "--device-rng"],
+                                  ["three_cart", "zero_order", "--iters", "1", "--T", "30", "--quiet"],
+                                  ["pendulum", "cem", "--iters", "2", "--T", "40", "--quiet"],
+                                  ["bicycle", "exact", "--iters", "1", "--T", "40", "--quiet"]])
+def test_example_runner(amd, argv, monkeypatch, capsys):
+    import examples.run as run
+    monkeypatch.setattr("sys.argv", ["run.py"] + argv)
+    run.main()
+    out = capsys.readouterr().out
+    hist = [float(v) for v in out.split("cost history:")[1].split()]
+    assert len(hist) == int(argv[3]) + 2 and all(np.isfinite(hist)) and hist[1] < hist[0]
