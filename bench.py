@@ -1,16 +1,20 @@
 #!/usr/bin/env python3
 """Headline benchmark: rollouts x timesteps / s of the randomised-smoothing pass
-(get_TV_matrices: sample pass + reduction + solve -> A_t,B_t,c_t) and iLQR
-iterations / s (that + Riccati + closed-loop rollout + cost), BASELINE.json configs[1]:
-pendulum zero-order, T=30, N=10000 samples per timestep PER GPU, samples resident in
-HBM (f32).  One process per GPU; N>1 is launched by torch.distributed.run.
+(get_TV_matrices: sample pass + reduction + solve -> A_t,B_t,c_t) and iLQR iterations / s
+(that + TV-LQR backward pass + closed-loop rollout + cost).
 
-    python bench.py --gpus 1 --steps 20000 --warmup 2000
+Default workload = the configuration BASELINE.json's metric is quoted on: planar_hand
+(quasi-dynamic contact, irs_lqr_quasistatic), T=50, N=10000 u-perturbations per timestep PER
+GPU, zero-order-B smoothing, samples resident in HBM (f32).  `--workload pendulum` runs
+BASELINE configs[1] (pendulum zero-order AB, T=30, N=10000), the HBM-bound case; the default run
+reports it too under "pendulum" so both kernels are tracked from one JSON line.
 
-A "step" = one smoothing pass over the (T x N) sample grid = ONE kernel launch on one
-GPU.  With --gpus N every rank holds its own N samples per timestep (weak scaling) and
-the (T,P) f64 statistics are all-reduced (RCCL) inside every step, followed by the
-solve launch.  Prints ONE JSON line on rank 0.
+    python bench.py --gpus 1 --steps 2000 --warmup 200
+
+A "step" = one smoothing pass over the (T x N) sample grid = ONE kernel launch on one GPU.  With
+--gpus N every rank holds its own N samples per timestep (weak scaling) and the (T,P) f64
+statistics are all-reduced (RCCL) inside every step, followed by the solve launch.  One process
+per GPU; N>1 is launched by torch.distributed.run.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -25,47 +29,113 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_F32_PEAK_TFLOPS = 157.3  # peak FP32 (vector), same guide
 
 
-def cpu_baseline(T, N, seconds=12.0):
-    """The oracle (NumPy restatement of irs_lqr_zero_order.py:38-63, same structure
-    as the reference: Python loop over t, vectorised dynamics_batch, SVD lstsq) timed
-    on ONE host core on the same workload shape.  Reported, never the target."""
-    from oracle import irs_oracle as orc
-    s = orc.PendulumOracle(0.05)
-    u = np.tile(np.array([0.1]), (T, 1))
-    x = orc.rollout(s, np.zeros(2), u)
+class Workload:
+    """Everything that differs between the benchmarked configurations."""
+
+    def __init__(self, name, T=None):
+        from irs_mpc_amd import PendulumDynamics, PlanarHandDynamics
+        from irs_mpc_amd import _lib
+        self.name = name
+        if name == "pendulum":
+            self.T = T or 30
+            self.system = PendulumDynamics(0.05)
+            self.mode, self.mode_name = _lib.SMOOTH_ZERO_ORDER_AB, "ZERO_ORDER_AB"
+            self.x0 = np.zeros(2)
+            self.u_trj = np.tile(np.array([0.1]), (self.T, 1))
+            self.Q, self.Qd, self.R = np.diag([1., 1.]), np.diag([20., 20.]), np.diag([1.])
+            self.xd = np.tile(np.array([np.pi, 0.]), (self.T + 1, 1))
+            self.std_x, self.std_u = 1.0, 1.0
+            self.label = "pendulum zero-order smoothing (BASELINE configs[1])"
+            self.kernel = "smooth_kernel<PendulumModel, ZERO_ORDER_AB>"
+            self.flops_per_sample = None
+        elif name == "planar_hand":
+            self.T = T or 50
+            self.system = PlanarHandDynamics(0.1)
+            self.mode, self.mode_name = _lib.SMOOTH_ZERO_ORDER_B, "ZERO_ORDER_B"
+            # examples/planar_hand/run_planar_hand.py:31-44 (initial grasp), :113-131 (costs, goal)
+            self.x0 = np.array([0.0, 0.35, 0.0, -np.pi / 4, -np.pi / 4, np.pi / 4, np.pi / 4])
+            self.u_trj = np.tile(self.x0[3:], (self.T, 1))
+            q = np.array([1e-3, 1e-3, 10.0, 1e-3, 1e-3, 1e-3, 1e-3])
+            self.Q, self.Qd, self.R = np.diag(q), np.diag(100 * q), 5.0 * np.eye(4)
+            self.xd = np.tile(self.x0 + np.array([0.3, -0.1, 0.5, 0, 0, 0, 0]), (self.T + 1, 1))
+            self.std_x, self.std_u = 0.0, 0.3          # run_planar_hand.py:146
+            self.label = "planar_hand quasi-dynamic contact, zero-order-B smoothing (the metric's config)"
+            self.kernel = "smooth_kernel<PlanarHandModel, ZERO_ORDER_B>"
+            # per one-step evaluation of the contact QP (csrc/contact_models.hpp; DESIGN.md 5):
+            # QP assembly ~1.5 kFLOP + 152 FLOP per PGS sweep + the Gram update
+            self.flops_per_sample = 1500 + 152 * int(self.system.pgs_iters) + 76
+        else:
+            raise ValueError(name)
+
+    def bytes_per_sample(self, n, m):
+        """the f32 perturbations are read once."""
+        return 4 * (m if self.name == "planar_hand" else n + m)
+
+    def oracle(self):
+        from oracle import irs_oracle as orc
+        return orc, (orc.PendulumOracle(0.05) if self.name == "pendulum" else orc.PlanarHandOracle(0.1))
+
+
+def cpu_baseline(w, N, seconds=12.0):
+    """The oracle (NumPy restatement with the reference's structure: Python loop over t,
+    vectorised dynamics_batch, SVD lstsq) timed on ONE host core on a bounded sample of the same
+    workload.  Reported, never the target."""
+    orc, s = w.oracle()
+    T = w.T
     rng = np.random.default_rng(0)
-    dx = rng.normal(size=(T, N, 2)).astype(np.float32).astype(np.float64)
-    du = rng.normal(size=(T, N, 1)).astype(np.float32).astype(np.float64)
-    orc.zero_order_TV(s, x, u, dx, du)
+    x = orc.rollout(s, w.x0, w.u_trj)
+    if w.name == "pendulum":
+        Ns = N
+        dx = rng.normal(size=(T, Ns, 2)).astype(np.float32).astype(np.float64)
+        du = rng.normal(size=(T, Ns, 1)).astype(np.float32).astype(np.float64)
+
+        def once():
+            orc.zero_order_TV(s, x, w.u_trj, dx, du)
+        what = "oracle.zero_order_TV"
+    else:
+        Ns = min(N, 2000)       # the vectorised PGS loop costs ~ms per 1000 samples per timestep
+        du = (w.std_u * rng.normal(size=(T, Ns, 4))).astype(np.float32).astype(np.float64)
+
+        def once():
+            orc.zero_order_B_decoupled(s, x, w.u_trj, du)
+        what = "oracle.zero_order_B_decoupled"
+    once()
     reps, t0 = 0, time.perf_counter()
     while True:
-        orc.zero_order_TV(s, x, u, dx, du)
+        once()
         reps += 1
         el = time.perf_counter() - t0
         if el > seconds or reps >= 2000:
             break
-    return {"value": T * N * reps / el, "unit": "rollouts*timesteps/s", "cores": 1, "kind": "port",
-            "sample": "%d passes of the same T=%d N=%d workload (oracle.zero_order_TV, supplied samples, "
-                      "1 thread, %.1f s)" % (reps, T, N, el),
+    return {"value": T * Ns * reps / el, "unit": "rollouts*timesteps/s", "cores": 1, "kind": "port",
+            "sample": "%d passes of T=%d N=%d of the same workload (%s, supplied samples, 1 thread, %.1f s)"
+                      % (reps, T, Ns, what, el),
             "host_cpus": os.cpu_count()}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20000)
-    ap.add_argument("--warmup", type=int, default=2000)
-    ap.add_argument("--T", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=None, help="default 2000 (planar_hand) / 20000 (pendulum)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="planar_hand", choices=["planar_hand", "pendulum"])
+    ap.add_argument("--T", type=int, default=None)
     ap.add_argument("--N", type=int, default=10000, help="samples per timestep per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the pendulum (configs[1]) sub-report")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="run all ranks on GPU 0 with gloo (exercises the N>1 code path on a 1-GPU box)")
     ap.add_argument("--sweep", action="store_true", help="also time N=1e3,1e5,1e6 (extra keys)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 20000 if args.workload == "pendulum" else 2000
+    if args.warmup is None:
+        args.warmup = max(1, args.steps // 10)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -81,19 +151,9 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    from irs_mpc_amd import PendulumDynamics, device as dev
-    from irs_mpc_amd._lib import SMOOTH_ZERO_ORDER_AB as MODE
+    from irs_mpc_amd import device as dev
     from irs_mpc_amd.distributed import all_reduce_sums
 
-    T = args.T
-    system = PendulumDynamics(0.05)
-    dm = system.dm()
-    n, m = dm.n, dm.m
-    Q, Qd, R = dev.to_dev(np.diag([1., 1.])), dev.to_dev(np.diag([20., 20.])), dev.to_dev(np.diag([1.]))
-    xd = dev.to_dev(np.tile(np.array([np.pi, 0.]), (T + 1, 1)))
-    x0 = dev.to_dev(np.zeros(2))
-    u_trj = dev.to_dev(np.tile(np.array([0.1]), (T, 1)))
-    x_trj, _ = dm.rollout_cost(x0, u_trj, Q, R, xd)
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
@@ -128,10 +188,18 @@ def main():
             el = float(t.item())
         return el, ev_ms
 
-    def run(N, steps, warmup):
+    def run(w, N, steps, warmup):
+        """Times the smoothing step and the full iLQR iteration of workload `w`."""
+        dm = w.system.dm()
+        n, m, T, MODE = dm.n, dm.m, w.T, w.mode
+        Q, Qd, R = dev.to_dev(w.Q), dev.to_dev(w.Qd), dev.to_dev(w.R)
+        xd, x0, u_trj = dev.to_dev(w.xd), dev.to_dev(w.x0), dev.to_dev(w.u_trj)
+        x_trj, _ = dm.rollout_cost(x0, u_trj, Q, R, xd)
         g = torch.Generator(device="cuda").manual_seed(1234 + rank)
-        dx = torch.randn((T, N, n), generator=g, device="cuda", dtype=torch.float32)
-        du = torch.randn((T, N, m), generator=g, device="cuda", dtype=torch.float32)
+        dx = None
+        if w.name == "pendulum":
+            dx = w.std_x * torch.randn((T, N, n), generator=g, device="cuda", dtype=torch.float32)
+        du = w.std_u * torch.randn((T, N, m), generator=g, device="cuda", dtype=torch.float32)
         n_total = N * world
         if world == 1:
             plan = dev.SmoothPlan(dm, MODE, x_trj, u_trj, dx=dx, du=du, fuse=True)
@@ -159,7 +227,8 @@ def main():
             descent.run(stream)
 
         el, ev_ms = timed(smooth_step, steps, warmup)
-        el_it, _ = timed(ilqr_step, steps, warmup)
+        el_it, _ = timed(ilqr_step, max(1, steps // 4), max(1, warmup // 4))
+        el_it *= steps / max(1, steps // 4)
         # Kernel time of the sample pass: HIP events recorded on the stream the kernel is
         # launched on (torch's current stream is the one handed to the C ABI), bracketing
         # `steps` launches of the timed region when the step is a single launch, otherwise
@@ -175,25 +244,42 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             k_ms = e0.elapsed_time(e1) / steps
-        return el, el_it, k_ms
+        info = int(tv["info"].abs().sum().item())
+        assert info == 0, "smoothing solve reported a non-SPD Gram matrix"
+        return el, el_it, k_ms, (n, m)
 
-    N = args.N
-    el, el_it, k_mean = run(N, args.steps, args.warmup)
-    bytes_per_sample_step = 4 * (n + m)            # dx,du read once, f32
-    alg_bytes = bytes_per_sample_step * N * T      # per launch (per GPU)
-    achieved = alg_bytes / (k_mean * 1e-3) / 1e9
+    def roofline(w, N, k_ms, nm):
+        alg_bytes = w.bytes_per_sample(*nm) * N * w.T      # per launch (per GPU)
+        hbm = alg_bytes / (k_ms * 1e-3) / 1e9
+        # HBM traffic per launch from the PMC passes of tools/profile_round.sh (separate rocprofv3
+        # --pmc runs of this same command; FETCH_SIZE doubled as the gfx950 note in
+        # MI355X_MICROARCH.md prescribes).
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc_path):
+            key = "%s_%s_T%d_N%d" % (w.name, "zero" if w.name == "pendulum" else "zeroB", w.T, N)
+            pmc = json.load(open(pmc_path)).get(key)
+            if pmc and "FETCH_SIZE_raw_avg" in pmc:
+                traffic = (2.0 * pmc["FETCH_SIZE_raw_avg"] + pmc.get("WRITE_SIZE_raw_avg", 0.0)) * 1024.0
+                traffic_src = "profiles/pmc_latest.json"
+        r = {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
+             "traffic": traffic, "traffic_source": traffic_src,
+             "kernel": w.kernel + " (sample pass + reduction + solve, one launch)",
+             "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k_ms,
+             "timing": "HIP event pair on the launch stream around the timed launches / launches"}
+        if w.flops_per_sample:
+            # the contact step is arithmetic on registers (PGS sweeps): f32 VALU is what bounds it
+            tf = w.flops_per_sample * N * w.T / (k_ms * 1e-3) / 1e12
+            r.update({"bound": "valu_f32", "achieved": tf, "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                      "frac": tf / VALU_F32_PEAK_TFLOPS, "alg_flops_per_launch": w.flops_per_sample * N * w.T,
+                      "hbm": {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS},
+                      "note": "no GEMM shape in a per-sample projected Gauss-Seidel solve: the bound is the f32 "
+                              "vector rate, not HBM or MFMA; the HBM view of the same launch is under 'hbm'"})
+        return r
 
-    # HBM traffic per launch from the PMC passes of tools/profile_round.sh (separate
-    # rocprofv3 --pmc runs of this same command; FETCH_SIZE doubled as the gfx950 note in
-    # MI355X_MICROARCH.md prescribes, and it then matches the known byte count).
-    traffic, traffic_src = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if os.path.exists(pmc_path):
-        pmc = json.load(open(pmc_path)).get("pendulum_zero_T%d_N%d" % (T, N))
-        if pmc and "FETCH_SIZE_raw_avg" in pmc:
-            traffic = (2.0 * pmc["FETCH_SIZE_raw_avg"] + pmc.get("WRITE_SIZE_raw_avg", 0.0)) * 1024.0
-            traffic_src = "profiles/pmc_latest.json"
-
+    w = Workload(args.workload, args.T)
+    N, T = args.N, w.T
+    el, el_it, k_mean, nm = run(w, N, args.steps, args.warmup)
     out = {
         "metric": "rollouts*timesteps/s (randomized-smoothing pass) + iLQR-iters/s",
         "value": world * N * T * args.steps / el,
@@ -202,29 +288,32 @@ def main():
         "ms_per_step": 1e3 * el / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "pendulum zero-order smoothing (BASELINE configs[1])", "T": T,
-                   "N_per_gpu": N, "N_total": N * world, "samples": "supplied, resident in HBM (f32)",
+        "config": {"workload": w.label, "T": T, "N_per_gpu": N, "N_total": N * world, "mode": w.mode_name,
+                   "samples": "supplied, resident in HBM (f32)",
                    "parallelism": "samples sharded over %d GPU(s), 1 all-reduce of (T,P) f64 per step" % world},
         "ilqr_iters_per_s": args.steps / el_it,
         "ms_per_ilqr_iter": 1e3 * el_it / args.steps,
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "smooth_kernel<PendulumModel, ZERO_ORDER_AB> (sample pass + reduction + solve, "
-                               "one launch)",
-                     "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k_mean,
-                     "timing": "HIP event pair on the launch stream around the timed launches / launches"},
+        "roofline": roofline(w, N, k_mean, nm),
     }
     if args.sweep and world == 1:
         sweep = {}
-        for Ns in (1000, 100000, 1000000):
+        for Ns in (1000, 100000) + ((1000000,) if w.name == "pendulum" else ()):
             st = max(20, args.steps // (4 if Ns <= 100000 else 16))
-            e, ei, km = run(Ns, st, 5)
+            e, ei, km, _ = run(w, Ns, st, 5)
             sweep[str(Ns)] = {"value": Ns * T * st / e, "ilqr_iters_per_s": st / ei,
-                              "kernel_GBps": bytes_per_sample_step * Ns * T / (km * 1e-3) / 1e9}
+                              "kernel_GBps": w.bytes_per_sample(*nm) * Ns * T / (km * 1e-3) / 1e9}
         out["sweep_N"] = sweep
+    if world == 1 and not args.no_secondary and w.name != "pendulum":
+        w2 = Workload("pendulum")
+        st2 = 10000
+        e2, ei2, km2, nm2 = run(w2, N, st2, 1000)
+        out["pendulum"] = {"config": {"workload": w2.label, "T": w2.T, "N_per_gpu": N, "mode": w2.mode_name},
+                           "value": N * w2.T * st2 / e2, "unit": "rollouts*timesteps/s", "steps": st2,
+                           "ms_per_step": 1e3 * e2 / st2, "ilqr_iters_per_s": st2 / ei2,
+                           "roofline": roofline(w2, N, km2, nm2)}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(T, N)
+            out["cpu_baseline"] = cpu_baseline(w, N)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -50,8 +50,14 @@ typedef enum irs_model_id {
     IRS_MODEL_QUADROTOR = 1,  /* examples/quadrotor/quadrotor_dynamics.py:15-231;
                                  params = {h, m, L, g, Ixx, Iyy, Izz, kF, kM}                          */
     IRS_MODEL_BICYCLE = 2,    /* examples/bicycle/bicycle_dynamics.py:8-132; params = {h}              */
-    IRS_MODEL_THREE_CART = 3  /* examples/three_cart/three_cart_dynamics.py:8-107 (scalar `dynamics`:
+    IRS_MODEL_THREE_CART = 3, /* examples/three_cart/three_cart_dynamics.py:8-107 (scalar `dynamics`:
                                  contact by branching); params = {h, d}                                */
+    IRS_MODEL_PLANAR_HAND = 4 /* examples/planar_hand (QuasistaticDynamics over the external simulator,
+                                 irs_lqr/quasistatic_dynamics.py:136-164): planar quasi-dynamic contact,
+                                 Anitescu convex step; q = [xo,yo,th, ql1,ql2, qr1,qr2], u = joint commands;
+                                 params = {h, g, mass, R, mu, kp1, kp2, l1, l2, r_link, base_x, pgs_iters};
+                                 no Jacobian: FIRST_ORDER / exact are unsupported, ZERO_ORDER_B returns the
+                                 decoupled (A,B) of irs_lqr_quasistatic.py:275-284.  PARITY UNPINNED.    */
 } irs_model_id;
 
 /* Smoothing estimators.                                                         */

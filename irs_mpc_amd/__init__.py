@@ -6,5 +6,6 @@ from .irs_lqr import (IrsLqr, IrsLqrExact, IrsLqrFirstOrder,        # noqa: F401
                       IrsLqrParameters, IrsLqrZeroOrder)
 from .sampling import GaussianSmoothing                             # noqa: F401
 from .systems import (BicycleDynamics, PendulumDynamics,             # noqa: F401
-                      QuadrotorDynamics, ThreeCartDynamics)
+                      PlanarHandDynamics, QuadrotorDynamics,
+                      ThreeCartDynamics)
 from .tv_lqr import get_solver, solve_tvlqr                         # noqa: F401

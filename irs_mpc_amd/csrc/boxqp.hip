@@ -381,6 +381,7 @@ size_t irs_tvlqr_box_lds_bytes(int model, int T) {
         case IRS_MODEL_QUADROTOR: return BoxLayout<12, 4>::doubles(T) * sizeof(double);
         case IRS_MODEL_BICYCLE: return BoxLayout<5, 2>::doubles(T) * sizeof(double);
         case IRS_MODEL_THREE_CART: return BoxLayout<6, 2>::doubles(T) * sizeof(double);
+        case IRS_MODEL_PLANAR_HAND: return BoxLayout<7, 4>::doubles(T) * sizeof(double);
     }
     return 0;
 }

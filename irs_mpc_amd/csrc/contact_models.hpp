@@ -1,0 +1,154 @@
+// Planar quasi-dynamic contact dynamics as device functors.
+//
+// The reference's contact examples (planar_hand, box_pivoting, ...) step an EXTERNAL
+// simulator, pangtao22/quasistatic_simulator (not vendored; call sites
+// irs_lqr/quasistatic_dynamics.py:136-164).  Its time-stepping scheme is Anitescu's convex
+// relaxation of quasi-dynamic contact (Pang & Tedrake 2021): each step solves
+//
+//     min_dq  1/2 dq_u' (M_u/h^2) dq_u - tau_u' dq_u  +  1/2 (q_a + dq_a - u)' K_a (q_a + dq_a - u)
+//     s.t.    phi_i + (n_i + mu d_ij)' J_i dq >= 0      for every contact i, friction generator j
+//
+// (unactuated DOFs regularised by their mass -- `is_quasi_dynamic=True`; actuated DOFs are
+// stiffness-controlled towards the command u; `nd_per_contact=2` generators in the plane), and
+// q+ = q + dq.  The only in-tree statement of the model is the 1-D toy of
+// examples/box_pushing/analysis/box_on_box.py:11-20 (w1 = m/(m+h^2 k), w2 = h^2 k/(m+h^2 k)),
+// which this QP reproduces.  Geometry constants come from the analysis plotters
+// (examples/planar_hand/analysis/planar_hand_analysis.py:33-101) and the set-up files.
+// PARITY UNPINNED: the simulator's model files (SDF/YAML: masses, friction) are not in the
+// tree, so these functors are checked against their own NumPy restatement only.
+//
+// The QP has a diagonal Hessian, so its dual is a small non-negative QP in the contact
+// multipliers, lam >= 0:  min 1/2 lam' W lam + r' lam,  W = J D^-1 J',  r = phi - J D^-1 b,
+// solved by projected Gauss-Seidel; dq = D^-1 (J' lam - b).
+#pragma once
+#include "dual.hpp"
+
+template <typename S>
+IRS_HD S irs_max0(const S& a) { return irs_value(a) > 0 ? a : S(a * (typename scalar_of<S>::type)(0)); }
+
+// examples/planar_hand: a disc (radius R) cradled by two 2-link arms with capsule links.
+//   q = [xo, yo, th, ql1, ql2, qr1, qr2]   (object first, then left / right joint angles)
+//   u = commanded joint angles [ql1, ql2, qr1, qr2]      (indices_u_into_x = 3..6)
+//   params = {h, g, mass, R, mu, kp1, kp2, l1, l2, r_link, base_x, pgs_iters}
+// Geometry (planar_hand_analysis.py:69-101): bases (-+base_x, 0); the left arm's first joint
+// angle is offset by pi; link lengths l1, l2; capsule radius r_link.
+struct PlanarHandModel {
+    static constexpr int NX = 7, NU = 4, NPARAMS = 12;
+    static constexpr int NC = 8;                 // 4 link-disc pairs x 2 friction generators
+    // no differentiable step here: ZERO_ORDER_B returns the decoupled (A,B) of
+    // IrsLqrQuasistatic.decouple_AB_matrices (irs_lqr_quasistatic.py:275-284) -- every contact
+    // example sets decouple_AB = True, which discards the sampled A anyway
+    static constexpr bool HAS_JACOBIAN = false;
+    IRS_HD static int u_into_x(int j) { return 3 + j; }
+
+    template <typename S>
+    IRS_HD static void step(const ModelParams& p, const S* q, const S* u, S* qn) {
+        using T = typename scalar_of<S>::type;
+        const T h = T(p.v[0]), g = T(p.v[1]), mass = T(p.v[2]), R = T(p.v[3]), mu = T(p.v[4]);
+        const T kp1 = T(p.v[5]), kp2 = T(p.v[6]), l1 = T(p.v[7]), l2 = T(p.v[8]), rl = T(p.v[9]), bx = T(p.v[10]);
+        const int iters = (int)p.v[11];
+        // diagonal QP Hessian D and linear term b
+        const T inertia = T(0.5) * mass * R * R;
+        T Dinv[NX];
+        Dinv[0] = h * h / mass; Dinv[1] = h * h / mass; Dinv[2] = h * h / inertia;
+        Dinv[3] = T(1) / kp1; Dinv[4] = T(1) / kp2; Dinv[5] = T(1) / kp1; Dinv[6] = T(1) / kp2;
+        S b[NX];
+        b[0] = q[0] * T(0);
+        b[1] = q[1] * T(0) + mass * g;           // -tau_u, tau_u = (0, -m g, 0)
+        b[2] = q[2] * T(0);
+        b[3] = kp1 * (q[3] - u[0]); b[4] = kp2 * (q[4] - u[1]);
+        b[5] = kp1 * (q[5] - u[2]); b[6] = kp2 * (q[6] - u[3]);
+
+        // contact rows: J (NC x NX), phi (NC)
+        S J[NC][NX], phi[NC];
+#pragma unroll
+        for (int arm = 0; arm < 2; ++arm) {
+            const T base = arm == 0 ? -bx : bx;
+            const S a1 = arm == 0 ? S(q[3] + T(3.14159265358979323846)) : q[5];
+            const S a2 = a1 + (arm == 0 ? q[4] : q[6]);
+            S s1, c1, s2, c2;
+            irs_sincos(a1, s1, c1);
+            irs_sincos(a2, s2, c2);
+            const S p1x = c1 * l1 + base, p1y = s1 * l1;      // second joint
+#pragma unroll
+            for (int link = 0; link < 2; ++link) {
+                // segment start a, direction (dx,dy), length L
+                const S ax = link == 0 ? S(c1 * T(0) + base) : p1x;
+                const S ay = link == 0 ? S(s1 * T(0)) : p1y;
+                const S dx = link == 0 ? c1 : c2, dy = link == 0 ? s1 : s2;
+                const T L = link == 0 ? l1 : l2;
+                S rx = q[0] - ax, ry = q[1] - ay;
+                S sp = rx * dx + ry * dy;                      // projection on the segment
+                const T spv = irs_value(sp);
+                if (spv < T(0)) sp = sp * T(0);
+                else if (spv > L) sp = sp * T(0) + L;
+                const S wx = ax + dx * sp, wy = ay + dy * sp;  // closest point on the axis
+                S nx = q[0] - wx, ny = q[1] - wy;
+                const S dist = irs_sqrt(nx * nx + ny * ny);
+                nx = nx / dist; ny = ny / dist;                // link -> object
+                const S gap = dist - (R + rl);
+                // contact point on the link surface, arms about the joints
+                const S cx = wx + nx * rl, cy = wy + ny * rl;
+                const S r1x = cx - base, r1y = cy;             // about the arm base (z x r = (-ry, rx))
+                const S r2x = cx - p1x, r2y = cy - p1y;        // about the second joint
+                const S tx = -ny, ty = nx;                     // tangent
+#pragma unroll
+                for (int gen = 0; gen < 2; ++gen) {
+                    const int row = (arm * 2 + link) * 2 + gen;
+                    const T sgn = gen == 0 ? mu : -mu;
+                    const S ex = nx + tx * sgn, ey = ny + ty * sgn;
+                    phi[row] = gap;
+                    // object: v = (dxo, dyo) + dth * z x (-R n)  ;  z x (-R n) = (R ny, -R nx)
+                    J[row][0] = ex;
+                    J[row][1] = ey;
+                    J[row][2] = (ex * ny - ey * nx) * R;
+                    // link point: -(q1' z x r1 [+ q2' z x r2])
+                    const S j1 = -(ey * r1x - ex * r1y);
+                    const S j2 = link == 1 ? S(-(ey * r2x - ex * r2y)) : S(ex * T(0));
+                    const S zero = ex * T(0);
+                    J[row][3] = arm == 0 ? j1 : zero;
+                    J[row][4] = arm == 0 ? j2 : zero;
+                    J[row][5] = arm == 1 ? j1 : zero;
+                    J[row][6] = arm == 1 ? j2 : zero;
+                }
+            }
+        }
+        // dual: W = J D^-1 J', r = phi - J D^-1 b
+        S W[NC][NC], r[NC], lam[NC], invW[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            S ri = phi[i];
+#pragma unroll
+            for (int k = 0; k < NX; ++k) ri = ri - J[i][k] * b[k] * Dinv[k];
+            r[i] = ri;
+            lam[i] = ri * T(0);
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                S w = J[i][0] * J[j][0] * Dinv[0];
+#pragma unroll
+                for (int k = 1; k < NX; ++k) w = w + J[i][k] * J[j][k] * Dinv[k];
+                W[i][j] = w;
+                W[j][i] = w;
+            }
+            invW[i] = S(T(1)) / W[i][i];
+        }
+        // projected Gauss-Seidel, fixed sweep count (deterministic, branch-free per sample)
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                S acc = r[i];
+#pragma unroll
+                for (int j = 0; j < NC; ++j) acc = acc + W[i][j] * lam[j];
+                const S cand = lam[i] - acc * invW[i];
+                lam[i] = irs_max0(cand);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            S f = -b[k];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) f = f + J[i][k] * lam[i];
+            qn[k] = q[k] + f * Dinv[k];
+        }
+    }
+};

@@ -152,4 +152,15 @@ IRS_DUAL_TK void irs_sincos(const Dual<T, K>& a, Dual<T, K>& s, Dual<T, K>& c) {
 }
 IRS_DUAL_TK Dual<T, K> irs_sin(const Dual<T, K>& a) { Dual<T, K> s, c; irs_sincos(a, s, c); return s; }
 IRS_DUAL_TK Dual<T, K> irs_cos(const Dual<T, K>& a) { Dual<T, K> s, c; irs_sincos(a, s, c); return c; }
+IRS_DUAL_TK Dual<T, K> irs_sqrt(const Dual<T, K>& a) {
+    Dual<T, K> r; r.v = sqrt(a.v);
+    const T g = T(0.5) / r.v;
+#pragma unroll
+    for (int i = 0; i < K; ++i) r.d[i] = g * a.d[i];
+    return r;
+}
 #undef IRS_DUAL_TK
+IRS_HD float irs_sqrt(float x) { return sqrtf(x); }
+IRS_HD double irs_sqrt(double x) { return sqrt(x); }
+// value-based selection (piecewise-smooth models): the derivative follows the chosen branch
+template <typename S> IRS_HD S irs_select(bool c, const S& a, const S& b) { return c ? a : b; }

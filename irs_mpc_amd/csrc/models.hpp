@@ -14,6 +14,7 @@ struct ModelParams {
 // examples/pendulum/pendulum_dynamics.py:46-60 -- semi-implicit Euler.
 struct PendulumModel {
     static constexpr int NX = 2, NU = 1, NPARAMS = 1;
+    static constexpr bool HAS_JACOBIAN = true;
     template <typename S>
     IRS_HD static void step(const ModelParams& p, const S* x, const S* u, S* xn) {
         using T = typename scalar_of<S>::type;
@@ -29,6 +30,7 @@ struct PendulumModel {
 // params = {h, m, L, g, Ixx, Iyy, Izz, kF, kM} (quadrotor_dynamics.py:22-37).
 struct QuadrotorModel {
     static constexpr int NX = 12, NU = 4, NPARAMS = 9;
+    static constexpr bool HAS_JACOBIAN = true;
     template <typename S>
     IRS_HD static void step(const ModelParams& p, const S* x, const S* u, S* xn) {
         using T = typename scalar_of<S>::type;
@@ -87,6 +89,7 @@ struct QuadrotorModel {
 // x = [x, y, heading, speed, steering angle], u = [acceleration, steering velocity].
 struct BicycleModel {
     static constexpr int NX = 5, NU = 2, NPARAMS = 1;
+    static constexpr bool HAS_JACOBIAN = true;
     template <typename S>
     IRS_HD static void step(const ModelParams& p, const S* x, const S* u, S* xn) {
         using T = typename scalar_of<S>::type;
@@ -109,6 +112,7 @@ struct BicycleModel {
 // Non-smooth: Jacobians (dual numbers) are those of the active branch.
 struct ThreeCartModel {
     static constexpr int NX = 6, NU = 2, NPARAMS = 2;
+    static constexpr bool HAS_JACOBIAN = true;
     template <typename S>
     IRS_HD static void step(const ModelParams& p, const S* x, const S* u, S* xn) {
         using T = typename scalar_of<S>::type;
@@ -139,6 +143,8 @@ struct ThreeCartModel {
         }
     }
 };
+
+#include "contact_models.hpp"
 
 // J (n x (n+m), row-major) = d step / d [x,u] at (x,u), T = float or double.
 template <class Model, typename T>

@@ -146,14 +146,26 @@ __device__ __forceinline__ void finalize_timestep(const ModelParams& p, const do
         for (int q = lane; q < n * d; q += 64) L.AB[q / d][q % d] = S[q] / n_total;
     } else {
         if constexpr (MODE == IRS_SMOOTH_ZERO_ORDER_B) {
-            // A = exact Jacobian at the nominal point (quasistatic_dynamics.py:254-256)
-            double J[n * d];
-            model_jacobian<Model, double>(p, x, u, f, J);
-            if (lane == 0) {
+            if constexpr (Model::HAS_JACOBIAN) {
+                // A = exact Jacobian at the nominal point (quasistatic_dynamics.py:254-256)
+                double J[n * d];
+                model_jacobian<Model, double>(p, x, u, f, J);
+                if (lane == 0) {
 #pragma unroll
-                for (int i = 0; i < n; ++i)
+                    for (int i = 0; i < n; ++i)
 #pragma unroll
-                    for (int k = 0; k < n; ++k) L.AB[i][k] = J[i * d + k];
+                        for (int k = 0; k < n; ++k) L.AB[i][k] = J[i * d + k];
+                }
+            } else {
+                // decouple_AB (irs_lqr_quasistatic.py:275-284): A = I with the actuated
+                // columns zeroed (the actuated rows of B become I after the fit, below)
+                Model::template step<double>(p, x, u, f);
+                for (int q = lane; q < n * n; q += 64) {
+                    int i = q / n, k = q % n;
+                    bool act = false;
+                    for (int j = 0; j < m; ++j) act = act || (Model::u_into_x(j) == k);
+                    L.AB[i][k] = (i == k && !act) ? 1.0 : 0.0;
+                }
             }
         } else {
             Model::template step<double>(p, x, u, f);
@@ -285,6 +297,10 @@ __device__ __forceinline__ void finalize_timestep(const ModelParams& p, const do
         }  // NZ > 4
     }
     wave_sync();
+    if constexpr (MODE == IRS_SMOOTH_ZERO_ORDER_B && !Model::HAS_JACOBIAN) {
+        for (int q = lane; q < m * m; q += 64) L.AB[Model::u_into_x(q / m)][n + q % m] = (q / m == q % m) ? 1.0 : 0.0;
+        wave_sync();
+    }
     for (int q = lane; q < n * n; q += 64) At[(size_t)t * n * n + q] = L.AB[q / n][q % n];
     for (int q = lane; q < n * m; q += 64) Bt[(size_t)t * n * m + q] = L.AB[q / m][n + q % m];
     if (lane < n) {
@@ -576,7 +592,8 @@ __global__ __launch_bounds__(64) void exact_linearize_kernel(ModelParams p, cons
     for (int i = 0; i < n; ++i) x[i] = x_trj[(size_t)t * n + i];
 #pragma unroll
     for (int j = 0; j < m; ++j) u[j] = u_trj[(size_t)t * m + j];
-    model_jacobian<Model, double>(p, x, u, f, J);
+    if constexpr (!Model::HAS_JACOBIAN) return;
+    else model_jacobian<Model, double>(p, x, u, f, J);
 #pragma unroll
     for (int i = 0; i < n; ++i) {
         double c = f[i];
@@ -681,6 +698,7 @@ bool is_light(int model, int mode) {
         case IRS_MODEL_QUADROTOR: return light_m<QuadrotorModel>(mode);
         case IRS_MODEL_BICYCLE: return light_m<BicycleModel>(mode);
         case IRS_MODEL_THREE_CART: return light_m<ThreeCartModel>(mode);
+        case IRS_MODEL_PLANAR_HAND: return light_m<PlanarHandModel>(mode);
     }
     return false;
 }
@@ -719,7 +737,10 @@ template <class Model>
 int launch_smooth(int mode, const SmoothArgs& a, bool rng, bool fuse, hipStream_t st) {
     switch (mode) {
         case IRS_SMOOTH_ZERO_ORDER_AB: launch_smooth_m<Model, IRS_SMOOTH_ZERO_ORDER_AB>(a, rng, fuse, st); break;
-        case IRS_SMOOTH_FIRST_ORDER: launch_smooth_m<Model, IRS_SMOOTH_FIRST_ORDER>(a, rng, fuse, st); break;
+        case IRS_SMOOTH_FIRST_ORDER:
+            if constexpr (Model::HAS_JACOBIAN) launch_smooth_m<Model, IRS_SMOOTH_FIRST_ORDER>(a, rng, fuse, st);
+            else return IRS_ERR_UNSUPPORTED;
+            break;
         case IRS_SMOOTH_ZERO_ORDER_B: launch_smooth_m<Model, IRS_SMOOTH_ZERO_ORDER_B>(a, rng, fuse, st); break;
         default: return IRS_ERR_UNSUPPORTED;
     }
@@ -734,7 +755,9 @@ int launch_finalize(int mode, const SmoothArgs& a, hipStream_t st) {
             hipLaunchKernelGGL((smooth_finalize_kernel<Model, IRS_SMOOTH_ZERO_ORDER_AB>), grid, block, 0, st, a);
             break;
         case IRS_SMOOTH_FIRST_ORDER:
-            hipLaunchKernelGGL((smooth_finalize_kernel<Model, IRS_SMOOTH_FIRST_ORDER>), grid, block, 0, st, a);
+            if constexpr (Model::HAS_JACOBIAN)
+                hipLaunchKernelGGL((smooth_finalize_kernel<Model, IRS_SMOOTH_FIRST_ORDER>), grid, block, 0, st, a);
+            else return IRS_ERR_UNSUPPORTED;
             break;
         case IRS_SMOOTH_ZERO_ORDER_B:
             hipLaunchKernelGGL((smooth_finalize_kernel<Model, IRS_SMOOTH_ZERO_ORDER_B>), grid, block, 0, st, a);
@@ -776,7 +799,13 @@ int smooth_common(int model, const double* params, int n_params, int mode, int T
         a.n_total = (double)out->n_total;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    IRS_DISPATCH_MODEL(model, { rc = launch_smooth<Model>(mode, a, rng, fuse, st); });
+    IRS_DISPATCH_MODEL(model, {
+        if (!Model::HAS_JACOBIAN && mode == IRS_SMOOTH_FIRST_ORDER) {
+            irs_set_error("irs_smooth: model %d has no differentiable step (FIRST_ORDER unsupported)", model);
+            return IRS_ERR_UNSUPPORTED;
+        }
+        rc = launch_smooth<Model>(mode, a, rng, fuse, st);
+    });
     if (rc != IRS_OK) return rc;
     IRS_CHECK_LAUNCH();
     return IRS_OK;
@@ -914,6 +943,7 @@ int irs_rng_samples(int n, int m, int T, int N, const double* std_x, const doubl
     else if (n == 12 && m == 4) hipLaunchKernelGGL((rng_samples_kernel<12, 4>), grid, block, 0, st, dx, du, a);
     else if (n == 5 && m == 2) hipLaunchKernelGGL((rng_samples_kernel<5, 2>), grid, block, 0, st, dx, du, a);
     else if (n == 6 && m == 2) hipLaunchKernelGGL((rng_samples_kernel<6, 2>), grid, block, 0, st, dx, du, a);
+    else if (n == 7 && m == 4) hipLaunchKernelGGL((rng_samples_kernel<7, 4>), grid, block, 0, st, dx, du, a);
     else { irs_set_error("irs_rng_samples: unsupported (n,m)=(%d,%d)", n, m); return IRS_ERR_UNSUPPORTED; }
     IRS_CHECK_LAUNCH();
     return IRS_OK;
@@ -948,6 +978,10 @@ int irs_exact_linearize(int model, const double* params, int n_params, int T, co
     if (rc != IRS_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     IRS_DISPATCH_MODEL(model, {
+        if (!Model::HAS_JACOBIAN) {
+            irs_set_error("irs_exact_linearize: model %d has no differentiable step", model);
+            return IRS_ERR_UNSUPPORTED;
+        }
         hipLaunchKernelGGL((exact_linearize_kernel<Model>), dim3((T + 63) / 64), dim3(64), 0, st, p,
                            x_trj, u_trj, At, Bt, ct, T);
     });

@@ -1097,6 +1097,7 @@ int irs_tvlqr_riccati(int n, int m, int T, const double* At, const double* Bt, c
     else if (n == 12 && m == 4) hipLaunchKernelGGL((riccati_kernel_t<12, 4>), dim3(1), dim3(64), 0, st, a);
     else if (n == 5 && m == 2) hipLaunchKernelGGL((riccati_kernel_t<5, 2>), dim3(1), dim3(64), 0, st, a);
     else if (n == 6 && m == 2) hipLaunchKernelGGL((riccati_kernel_t<6, 2>), dim3(1), dim3(64), 0, st, a);
+    else if (n == 7 && m == 4) hipLaunchKernelGGL((riccati_kernel_t<7, 4>), dim3(1), dim3(64), 0, st, a);
     else hipLaunchKernelGGL(riccati_kernel, dim3(1), dim3(64), 0, st, a);
     IRS_CHECK_LAUNCH();
     return IRS_OK;

@@ -1,5 +1,6 @@
 """Device-backed twins of the reference's analytic example plugins."""
-from ._lib import MODEL_BICYCLE, MODEL_PENDULUM, MODEL_QUADROTOR, MODEL_THREE_CART
+from ._lib import (MODEL_BICYCLE, MODEL_PENDULUM, MODEL_PLANAR_HAND, MODEL_QUADROTOR,
+                   MODEL_THREE_CART)
 from .dynamical_system import DynamicalSystem
 
 
@@ -62,3 +63,37 @@ class ThreeCartDynamics(DynamicalSystem):
 
     def device_params(self):
         return [self.h, self.d]
+
+
+class PlanarHandDynamics(DynamicalSystem):
+    """Device twin of `QuasistaticDynamics` (irs_lqr/quasistatic_dynamics.py:15-164) for the
+    planar hand of examples/planar_hand (planar_hand_setup.py:8-27): a disc cradled by two
+    2-link arms, q = [xo, yo, th, ql1, ql2, qr1, qr2], u = commanded joint angles.  Steps the
+    Anitescu convex quasi-dynamic QP on the device (csrc/contact_models.hpp); the reference steps
+    the external quasistatic_simulator, so parity for this model is UNPINNED.  No Jacobian:
+    `jacobian_xu*` raise, `ZERO_ORDER_B` smoothing returns the decoupled (A,B)."""
+    device_model = MODEL_PLANAR_HAND
+
+    def __init__(self, h, mass=1.0, mu=0.5, pgs_iters=50):
+        super().__init__()
+        self.h = h
+        self.dim_x = 7
+        self.dim_u = 4
+        self.g = 10.0            # planar_hand_setup.py:23
+        self.mass = mass
+        self.R = 0.25            # planar_hand_setup.py:8
+        self.mu = mu
+        self.kp = (50.0, 25.0)   # planar_hand_setup.py:12
+        self.l1, self.l2 = 0.3, 0.2
+        self.r_link = 0.05
+        self.base_x = 0.1
+        self.pgs_iters = pgs_iters
+
+    def get_u_indices_into_x(self):
+        """quasistatic_dynamics.py:57-65."""
+        import numpy as np
+        return np.array([3, 4, 5, 6])
+
+    def device_params(self):
+        return [self.h, self.g, self.mass, self.R, self.mu, self.kp[0], self.kp[1], self.l1, self.l2,
+                self.r_link, self.base_x, float(self.pgs_iters)]

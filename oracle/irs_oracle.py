@@ -271,8 +271,146 @@ class ThreeCartOracle:
         return np.stack([self.jacobian_xu(x[i], u[i]) for i in range(x.shape[0])])
 
 
+class PlanarHandOracle:
+    """Planar quasi-dynamic contact step for examples/planar_hand (call sites
+    irs_lqr/quasistatic_dynamics.py:136-164; set-up examples/planar_hand/planar_hand_setup.py:8-27;
+    geometry examples/planar_hand/analysis/planar_hand_analysis.py:33-101).
+
+    PARITY UNPINNED: the reference steps pangtao22/quasistatic_simulator (external, not vendored,
+    its SDF/YAML model files are absent), so this restates the PUBLISHED scheme -- Anitescu's convex
+    quasi-dynamic step (Pang & Tedrake 2021), the in-tree 1-D instance of which is
+    examples/box_pushing/analysis/box_on_box.py:11-20 -- on the plotters' geometry:
+
+        min_dq 1/2 dq' D dq + b' dq   s.t.  phi_i + J_i dq >= 0,    q+ = q + dq
+        D = diag(M_u / h^2, K_a),  b = (-tau_u, K_a (q_a - u))
+
+    q = [xo, yo, th, ql1, ql2, qr1, qr2], u = commanded joint angles.  `dynamics` solves the dual
+    by `pgs_iters` projected Gauss-Seidel sweeps (what the device functor does, same order);
+    `dynamics_exact` solves the same QP to optimality (active-set via NNLS) as the physics check.
+    """
+
+    def __init__(self, h, mass=1.0, mu=0.5, pgs_iters=50):
+        self.h = h
+        self.dim_x, self.dim_u = 7, 4
+        self.g = 10.0            # planar_hand_setup.py:23
+        self.mass = mass
+        self.R = 0.25            # sphere_yz_rotation_r_0.25m (planar_hand_setup.py:8)
+        self.mu = mu
+        self.kp = (50.0, 25.0)   # planar_hand_setup.py:12
+        self.l1, self.l2 = 0.3, 0.2
+        self.r_link = 0.05
+        self.base_x = 0.1
+        self.pgs_iters = pgs_iters
+        self.indices_u_into_x = np.array([3, 4, 5, 6])
+
+    def params(self):
+        return [self.h, self.g, self.mass, self.R, self.mu, self.kp[0], self.kp[1], self.l1, self.l2,
+                self.r_link, self.base_x, self.pgs_iters]
+
+    def _qp(self, q, u):
+        """Batched QP data: Dinv (7,), b (B,7), J (B,8,7), phi (B,8)."""
+        q = np.atleast_2d(q)
+        u = np.atleast_2d(u)
+        B = q.shape[0]
+        h, m, R, mu = self.h, self.mass, self.R, self.mu
+        kp1, kp2 = self.kp
+        Dinv = np.array([h * h / m, h * h / m, h * h / (0.5 * m * R * R), 1 / kp1, 1 / kp2, 1 / kp1, 1 / kp2])
+        b = np.zeros((B, 7))
+        b[:, 1] = m * self.g
+        b[:, 3] = kp1 * (q[:, 3] - u[:, 0])
+        b[:, 4] = kp2 * (q[:, 4] - u[:, 1])
+        b[:, 5] = kp1 * (q[:, 5] - u[:, 2])
+        b[:, 6] = kp2 * (q[:, 6] - u[:, 3])
+        J = np.zeros((B, 8, 7))
+        phi = np.zeros((B, 8))
+        for arm in range(2):
+            base = -self.base_x if arm == 0 else self.base_x
+            a1 = q[:, 3] + np.pi if arm == 0 else q[:, 5]
+            a2 = a1 + (q[:, 4] if arm == 0 else q[:, 6])
+            s1, c1, s2, c2 = np.sin(a1), np.cos(a1), np.sin(a2), np.cos(a2)
+            p1x, p1y = c1 * self.l1 + base, s1 * self.l1
+            for link in range(2):
+                ax, ay = (np.full(B, base), np.zeros(B)) if link == 0 else (p1x, p1y)
+                dx, dy = (c1, s1) if link == 0 else (c2, s2)
+                L = self.l1 if link == 0 else self.l2
+                sp = np.clip((q[:, 0] - ax) * dx + (q[:, 1] - ay) * dy, 0.0, L)
+                wx, wy = ax + dx * sp, ay + dy * sp
+                nx, ny = q[:, 0] - wx, q[:, 1] - wy
+                dist = np.sqrt(nx * nx + ny * ny)
+                nx, ny = nx / dist, ny / dist
+                gap = dist - (R + self.r_link)
+                cx, cy = wx + nx * self.r_link, wy + ny * self.r_link
+                r1x, r1y = cx - base, cy
+                r2x, r2y = cx - p1x, cy - p1y
+                tx, ty = -ny, nx
+                for gen in range(2):
+                    row = (arm * 2 + link) * 2 + gen
+                    sg = mu if gen == 0 else -mu
+                    ex, ey = nx + tx * sg, ny + ty * sg
+                    phi[:, row] = gap
+                    J[:, row, 0] = ex
+                    J[:, row, 1] = ey
+                    J[:, row, 2] = (ex * ny - ey * nx) * R
+                    j1 = -(ey * r1x - ex * r1y)
+                    j2 = -(ey * r2x - ex * r2y) if link == 1 else np.zeros(B)
+                    J[:, row, 3 + 2 * arm] = j1
+                    J[:, row, 4 + 2 * arm] = j2
+        return Dinv, b, J, phi
+
+    def dynamics_batch(self, x, u):
+        Dinv, b, J, phi = self._qp(x, u)
+        W = np.einsum("bik,k,bjk->bij", J, Dinv, J)
+        r = phi - np.einsum("bik,k,bk->bi", J, Dinv, b)
+        lam = np.zeros_like(r)
+        invW = 1.0 / np.einsum("bii->bi", W)
+        for _ in range(int(self.pgs_iters)):
+            for i in range(8):
+                acc = r[:, i] + np.einsum("bj,bj->b", W[:, i], lam)
+                lam[:, i] = np.maximum(lam[:, i] - acc * invW[:, i], 0.0)
+        return np.atleast_2d(x) + (np.einsum("bik,bi->bk", J, lam) - b) * Dinv
+
+    def dynamics(self, x, u):
+        return self.dynamics_batch(x[None], u[None])[0]
+
+    def dynamics_exact(self, x, u):
+        """The same QP solved to optimality: the dual min 1/2|D^-1/2 (J' lam - b)|^2 + phi' lam,
+        lam >= 0, is an NNLS problem after completing the square on range(J D^-1/2)."""
+        from scipy.optimize import minimize
+        Dinv, b, J, phi = self._qp(x, u)
+        Dinv, b, J, phi = Dinv, b[0], J[0], phi[0]
+        W = (J * Dinv).dot(J.T)
+        r = phi - (J * Dinv).dot(b)
+        res = minimize(lambda l: 0.5 * l.dot(W).dot(l) + r.dot(l), np.zeros(8), jac=lambda l: W.dot(l) + r,
+                       bounds=[(0, None)] * 8, method="L-BFGS-B", options={"ftol": 1e-15, "gtol": 1e-12,
+                                                                             "maxiter": 10000})
+        return x + (J.T.dot(res.x) - b) * Dinv
+
+    def jacobian_xu(self, x, u):
+        raise NotImplementedError("no differentiable step; see zero_order_B_decoupled")
+
+    jacobian_xu_batch = jacobian_xu
+
+
+def zero_order_B_decoupled(system, x_trj, u_trj, du):
+    """calc_B_zero_order (irs_lqr/quasistatic_dynamics.py:242-266, u-only noise) followed by
+    decouple_AB_matrices (irs_lqr/irs_lqr_quasistatic.py:275-284): A = I with the actuated columns
+    zeroed, the actuated rows of B = I; c = f - A x - B u (irs_lqr_quasistatic.py:313-316)."""
+    T, n, m = u_trj.shape[0], system.dim_x, system.dim_u
+    idx = system.indices_u_into_x
+    At, Bt, ct = np.zeros((T, n, n)), np.zeros((T, n, m)), np.zeros((T, n))
+    for t in range(T):
+        ft = system.dynamics(x_trj[t], u_trj[t])
+        fdt = system.dynamics_batch(np.tile(x_trj[t], (du.shape[1], 1)), u_trj[t] + du[t])
+        Bt[t] = zero_order_B_fit(du[t], fdt - ft)
+        Bt[t][idx, :] = np.eye(m)
+        At[t] = np.eye(n)
+        At[t][:, idx] = 0.0
+        ct[t] = ft - At[t].dot(x_trj[t]) - Bt[t].dot(u_trj[t])
+    return At, Bt, ct
+
+
 SYSTEMS = {"pendulum": PendulumOracle, "quadrotor": QuadrotorOracle, "bicycle": BicycleOracle,
-           "three_cart": ThreeCartOracle}
+           "three_cart": ThreeCartOracle, "planar_hand": PlanarHandOracle}
 
 
 # --------------------------------------------------------------------------

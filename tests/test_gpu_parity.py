@@ -704,3 +704,80 @@ def test_example_runner(amd, argv, monkeypatch, capsys):
     out = capsys.readouterr().out
     hist = [float(v) for v in out.split("cost history:")[1].split()]
     assert len(hist) == int(argv[3]) + 2 and all(np.isfinite(hist)) and hist[1] < hist[0]
+
+
+# ---------------------------------------------------------------- planar quasi-dynamic contact (a7, unpinned)
+def _hand_setup(amd, T, settle=4):
+    sys_d, sys_o = amd.PlanarHandDynamics(0.1), orc.PlanarHandOracle(0.1)
+    x0 = np.array([0.0, 0.35, 0.0, -np.pi / 4, -np.pi / 4, np.pi / 4, np.pi / 4])   # run_planar_hand.py:31-44
+    for _ in range(settle):
+        x0 = sys_o.dynamics(x0, x0[3:] * 0 + np.array([-np.pi / 4, -np.pi / 4, np.pi / 4, np.pi / 4]))
+    u_trj = np.tile(x0[3:], (T, 1)) + 0.02 * np.sin(np.arange(T))[:, None] * np.array([1, -1, -1, 1])
+    return sys_d, sys_o, x0, u_trj
+
+
+def test_planar_hand_dynamics_vs_oracle(amd):
+    """The device functor's QP assembly + PGS sweeps reproduce the NumPy restatement (f64)."""
+    sys_d, sys_o, x0, _ = _hand_setup(amd, 1)
+    rng = np.random.default_rng(11)
+    X = x0 + 0.03 * rng.normal(size=(512, 7))
+    U = x0[3:] + 0.1 * rng.normal(size=(512, 4))
+    got = sys_d.dynamics_batch(X, U)
+    np.testing.assert_allclose(got, sys_o.dynamics_batch(X, U), rtol=0, atol=1e-10)
+    np.testing.assert_allclose(sys_d.dynamics(X[0], U[0]), sys_o.dynamics(X[0], U[0]), rtol=0, atol=1e-10)
+    with pytest.raises(Exception):
+        sys_d.jacobian_xu(X[0], U[0])
+
+
+def test_planar_hand_zero_order_B_decoupled_vs_oracle(amd):
+    """calc_B_zero_order + decouple_AB_matrices (quasistatic_dynamics.py:242-266,
+    irs_lqr_quasistatic.py:275-284) on the contact functor."""
+    from irs_mpc_amd import device as dev
+    from irs_mpc_amd._lib import SMOOTH_ZERO_ORDER_B
+    T, N = 6, 2000
+    sys_d, sys_o, x0, u_trj = _hand_setup(amd, T)
+    x_trj = orc.rollout(sys_o, x0, u_trj)
+    rng = np.random.default_rng(12)
+    du = (rng.normal(size=(T, N, 4)) * 0.1).astype(np.float32)
+    dm = sys_d.dm()
+    xd, ud = dev.to_dev(x_trj), dev.to_dev(u_trj)
+    o = dm.smooth(SMOOTH_ZERO_ORDER_B, xd, ud, None, dev.to_dev(du, dev.F32))
+    At, Bt, ct = o["At"], o["Bt"], o["ct"]
+    assert int(o["info"].abs().sum().item()) == 0
+    Ao, Bo, co = orc.zero_order_B_decoupled(sys_o, x_trj, u_trj, du.astype(np.float64))
+    np.testing.assert_allclose(At.cpu().numpy(), Ao, rtol=0, atol=0)
+    # f32 sample path incl. 50 PGS sweeps per sample vs the f64 oracle
+    np.testing.assert_allclose(Bt.cpu().numpy(), Bo, rtol=0, atol=2e-4)
+    np.testing.assert_allclose(ct.cpu().numpy(), co, rtol=0, atol=2e-4)
+    # the object rows of B see the contacts: pushing the fingers in moves the disc
+    assert np.abs(Bo[:, :3, :]).max() > 0.05
+    # first-order smoothing is refused for a model without a Jacobian
+    with pytest.raises(Exception):
+        dm.smooth(1, xd, ud, dev.to_dev(np.zeros((T, N, 7), np.float32), dev.F32), dev.to_dev(du, dev.F32))
+
+
+def test_planar_hand_descent_runs(amd):
+    """smooth -> Riccati -> closed-loop rollout through the contact functor in f64 == oracle."""
+    from irs_mpc_amd import device as dev
+    from irs_mpc_amd._lib import SMOOTH_ZERO_ORDER_B
+    T, N = 10, 1000
+    sys_d, sys_o, x0, u_trj = _hand_setup(amd, T)
+    x_trj = orc.rollout(sys_o, x0, u_trj)
+    rng = np.random.default_rng(13)
+    du = (rng.normal(size=(T, N, 4)) * 0.1).astype(np.float32)
+    dm = sys_d.dm()
+    o = dm.smooth(SMOOTH_ZERO_ORDER_B, dev.to_dev(x_trj), dev.to_dev(u_trj), None, dev.to_dev(du, dev.F32))
+    At, Bt, ct = o["At"], o["Bt"], o["ct"]
+    Q = np.diag([1e-3, 1e-3, 10, 1e-3, 1e-3, 1e-3, 1e-3])          # run_planar_hand.py:113-121
+    R = 5.0 * np.eye(4)
+    xd = np.tile(x0 + np.array([0.0, 0.0, 0.3, 0, 0, 0, 0]), (T + 1, 1))
+    out = dm.tvlqr_descent(At, Bt, ct, dev.to_dev(Q), dev.to_dev(100 * Q), dev.to_dev(R), dev.to_dev(xd),
+                           dev.to_dev(x0))
+    K, k, x_new, cost = out["K"], out["k"], out["x_new"], out["cost"]
+    assert int(out["info"].item()) == 0
+    A_, B_, c_ = At.cpu().numpy(), Bt.cpu().numpy(), ct.cpu().numpy()
+    Ko, ko = orc.tvlqr_riccati(A_, B_, c_, Q, 100 * Q, R, xd)
+    np.testing.assert_allclose(K.cpu().numpy(), Ko, rtol=1e-7, atol=1e-9)
+    xo, uo = orc.closed_loop_rollout(sys_o, K.cpu().numpy(), k.cpu().numpy(), x0)
+    np.testing.assert_allclose(x_new.cpu().numpy(), xo, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(float(cost.item()), orc.evaluate_cost(xo, uo, xd, Q, R), rtol=1e-9)

@@ -304,3 +304,48 @@ def test_device_gaussian_moments():
     assert np.abs(z.mean(0)).max() < 0.02
     np.testing.assert_allclose(z.std(0), [1.0, 0.5, 2.0], rtol=0.02)
     assert np.abs(np.corrcoef(z.T) - np.eye(3)).max() < 0.02
+
+
+# ---------------------------------------------------------------- planar quasi-dynamic contact (unpinned)
+def _hand_x0():
+    # examples/planar_hand/run_planar_hand.py:31-44
+    return np.array([0.0, 0.35, 0.0, -np.pi / 4, -np.pi / 4, np.pi / 4, np.pi / 4])
+
+
+def test_planar_hand_free_fall_and_servo():
+    """No contact: the disc moves by -g h^2 (quasi-dynamic, zero initial velocity) and the joints
+    reach their commands exactly (stiffness-only actuated rows)."""
+    o = orc.PlanarHandOracle(0.1)
+    x = _hand_x0()
+    x[1] = 2.0                                  # far above the hand
+    u = x[3:] + np.array([0.05, -0.02, 0.03, 0.01])
+    xn = o.dynamics(x, u)
+    np.testing.assert_allclose(xn[:3], [0.0, 2.0 - 10.0 * 0.1 ** 2, 0.0], atol=1e-14)
+    np.testing.assert_allclose(xn[3:], u, atol=1e-14)
+
+
+def test_planar_hand_pgs_converges_to_exact_qp_and_stays_feasible():
+    rng = np.random.default_rng(3)
+    o = orc.PlanarHandOracle(0.1, pgs_iters=2000)
+    x = _hand_x0()
+    u = x[3:].copy()
+    for _ in range(5):
+        x = o.dynamics(x, u)                    # settle into the cradle
+    for _ in range(10):
+        xs = x + 0.02 * rng.normal(size=7)
+        us = u + 0.1 * rng.normal(size=4)
+        xn = o.dynamics(xs, us)
+        np.testing.assert_allclose(xn, o.dynamics_exact(xs, us), atol=5e-7)
+        # linearised non-penetration holds at the optimum
+        Dinv, b, J, phi = o._qp(xs, us)
+        assert np.all(phi[0] + J[0].dot(xn - xs) > -1e-8)
+
+
+def test_planar_hand_symmetric_grasp_stays_symmetric():
+    o = orc.PlanarHandOracle(0.1, pgs_iters=2000)
+    x = _hand_x0()
+    for _ in range(3):
+        x = o.dynamics(x, _hand_x0()[3:])
+    assert abs(x[0]) < 1e-9 and abs(x[2]) < 1e-9
+    np.testing.assert_allclose(x[3:5], -x[5:7], atol=1e-9)
+    assert 0.30 < x[1] < 0.35                   # resting in the cradle, not through it

@@ -17,18 +17,22 @@ from irs_mpc_amd import PendulumDynamics, QuadrotorDynamics, device as dev, _lib
 model, mode_s, T, N = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 rng_mode = len(sys.argv) > 5 and "rng" in sys.argv[5:]
 fuse = "nofuse" not in sys.argv[5:]
-from irs_mpc_amd import BicycleDynamics, ThreeCartDynamics  # noqa: E402
+from irs_mpc_amd import BicycleDynamics, PlanarHandDynamics, ThreeCartDynamics  # noqa: E402
 sysd = {"pendulum": PendulumDynamics(0.05), "quadrotor": QuadrotorDynamics(0.05), "bicycle": BicycleDynamics(0.1),
-        "three_cart": ThreeCartDynamics(0.05)}[model]
+        "three_cart": ThreeCartDynamics(0.05), "planar_hand": PlanarHandDynamics(0.1)}[model]
 mode = {"zero": _lib.SMOOTH_ZERO_ORDER_AB, "first": _lib.SMOOTH_FIRST_ORDER, "zeroB": _lib.SMOOTH_ZERO_ORDER_B}[mode_s]
 dm = sysd.dm()
 n, m = dm.n, dm.m
 u0 = 0.1 if model == "pendulum" else 2.0
 std = 1.0 if model == "pendulum" else 0.1
 u_trj = dev.to_dev(np.full((T, m), u0))
+x0 = np.zeros(n)
+if model == "planar_hand":      # examples/planar_hand/run_planar_hand.py:31-44
+    x0 = np.array([0.0, 0.35, 0.0, -np.pi / 4, -np.pi / 4, np.pi / 4, np.pi / 4])
+    u_trj = dev.to_dev(np.tile(x0[3:], (T, 1)))
 Q, R = dev.to_dev(np.eye(n)), dev.to_dev(np.eye(m))
 xd = dev.to_dev(np.zeros((T + 1, n)))
-x_trj, _ = dm.rollout_cost(dev.to_dev(np.zeros(n)), u_trj, Q, R, xd)
+x_trj, _ = dm.rollout_cost(dev.to_dev(x0), u_trj, Q, R, xd)
 if rng_mode:
     plan = dev.SmoothPlan(dm, mode, x_trj, u_trj, rng=dict(N=N, std_x=[std] * n, std_u=[std] * m, seed=1, iter=1), fuse=fuse)
 else:
