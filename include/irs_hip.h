@@ -233,6 +233,31 @@ int irs_tvlqr_box_descent(int model, const double *params, int n_params, int T,
                           double *x_new, double *u_new, int *info, void *stream);
 size_t irs_tvlqr_box_lds_bytes(int model, int T);
 
+/* IrsLqrQuasistatic.local_descent after get_TV_matrices (irs_lqr/irs_lqr_quasistatic.py:286-345)
+ * for a position-controlled model (one with indices_u_into_x, e.g. IRS_MODEL_PLANAR_HAND): T tail
+ * re-solves of solve_tvlqr(..., indices_u_into_x, x_bound_abs, u_bound_abs, u_bound_rel)
+ * (irs_lqr/tv_lqr.py:30-137), first control applied to the true dynamics, plus eval_cost
+ * (:153-194) of the new trajectory.  The input cost is du_t'R du_t with du_t = u_t - u_{t-1},
+ * du_0 = u_0 - x_0[indices_u_into_x] (tv_lqr.py:98-108); inside each tail re-solve "u_{-1}" is
+ * the realised actuated position.  Solved as the box-LQR of the augmented state [x; u_prev] with
+ * the ADMM of irs_tvlqr_box_descent.
+ * Bounds, all DEV f64, NULL = absent, +-inf entries allowed:
+ *   x_lo,x_hi (T+1,n): ABSOLUTE bounds on x_t   (the caller adds the nominal trajectory to the
+ *   u_lo,u_hi (T,m)  : ABSOLUTE bounds on u_t    reference's trust-region offsets, :303-314)
+ *   du_lo,du_hi (T,m): bounds on u_t - u_{t-1}  (u_bounds_rel, :321-325)
+ * x_bound_rel is not supported ("should be rarely used", :315-319).
+ * cost (1) DEV (may be NULL); info (3) as irs_tvlqr_box_descent.                              */
+int irs_quasistatic_box_descent(int model, const double *params, int n_params, int T,
+                                const double *At, const double *Bt, const double *ct,
+                                const double *Q, const double *Qd, const double *R,
+                                const double *xd_trj, const double *x0,
+                                const double *x_lo, const double *x_hi,
+                                const double *u_lo, const double *u_hi,
+                                const double *du_lo, const double *du_hi,
+                                double rho, double relax, int max_iter, double eps,
+                                double *x_new, double *u_new, double *cost, int *info, void *stream);
+size_t irs_quasistatic_box_lds_bytes(int model, int T);
+
 /* ---- Cross-entropy-method baseline (irs_lqr/cem.py:151-184) -------------------- */
 
 /* Steps 1-2 of CrossEntropyMethod.local_descent (cem.py:163-168): roll out each of the

@@ -4,6 +4,8 @@ from .cem import CemParameters, CrossEntropyMethod                  # noqa: F401
 from .dynamical_system import DynamicalSystem                       # noqa: F401
 from .irs_lqr import (IrsLqr, IrsLqrExact, IrsLqrFirstOrder,        # noqa: F401
                       IrsLqrParameters, IrsLqrZeroOrder)
+from .irs_lqr_quasistatic import (IrsLqrQuasistatic,               # noqa: F401
+                                   IrsLqrQuasistaticParameters)
 from .sampling import GaussianSmoothing                             # noqa: F401
 from .systems import (BicycleDynamics, PendulumDynamics,             # noqa: F401
                       PlanarHandDynamics, QuadrotorDynamics,

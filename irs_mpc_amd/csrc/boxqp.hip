@@ -13,7 +13,19 @@
 // Restated in oracle/irs_oracle.py (tvlqr_box_factor / tvlqr_box_solve / local_descent_box),
 // whose solutions are certified against the QP's KKT conditions.
 //
+//
+// Position-controlled (quasistatic) variant, DU = true: IrsLqrQuasistatic.local_descent
+// (irs_lqr/irs_lqr_quasistatic.py:286-345) calls solve_tvlqr with indices_u_into_x, whose cost is
+// on du_t = u_t - u_{t-1} (du_0 = u_0 - x_0[idx], irs_lqr/tv_lqr.py:98-108, full R: alpha = 1) and
+// whose bounds are per-time trust regions (x_bound_abs, u_bound_abs) and rate limits
+// (u_bound_rel).  That QP is the SAME box-LQR in the augmented state z = [x; u_prev] with control
+// v = du:  z+ = [[A,B],[0,I]] z + [B;I] v + [c;0],  cost (x-xd)'Q(x-xd) + v'Rv,  box on z
+// (x bounds; u bounds = bounds on the u_prev block one step later) and on v.  The augmented
+// matrices are never materialised: accessors below read (A,B,c) directly.
+//
 // One wave, f64, everything in (dynamic) LDS: a latency-bound chain like the Riccati pass.
+#include <type_traits>
+
 #include "irs_common.hpp"
 
 namespace {
@@ -32,8 +44,12 @@ __device__ __forceinline__ double wave_max(double v) {
 struct BoxArgs {
     ModelParams p;
     const double *At, *Bt, *ct, *Q, *Qd, *R, *xd, *x0;
-    const double *xlo, *xhi, *ulo, *uhi;     // (n), (n), (m), (m); +-inf = unbounded
-    double *x_new, *u_new, *cost;
+    // bounds: row t at ptr + t * stride (stride 0 = one constant row); null = unbounded; +-inf ok
+    const double *xlo, *xhi;                 // on x_t, t = 0..T   (row 0 unused: x_0 is fixed)
+    const double *ulo, *uhi;                 // on u_t, t = 0..T-1
+    const double *dlo, *dhi;                 // DU only: on u_t - u_{t-1}
+    int sx, su, sd;
+    double *x_new, *u_new, *cost;            // cost may be null
     int* info;                               // [0] Hessian not PD at t+1, [1] max ADMM iterations used,
                                              // [2] number of tail problems that hit max_iter
     double alpha, rho, relax, eps;
@@ -51,10 +67,45 @@ struct BoxLayout {
     }
 };
 
-template <class Model>
+template <class M, class = void>
+struct has_u_into_x : std::false_type {};
+template <class M>
+struct has_u_into_x<M, std::void_t<decltype(M::u_into_x(0))>> : std::true_type {};
+
+template <class Model, bool DU>
 __global__ __launch_bounds__(64) void box_descent_kernel(BoxArgs a) {
-    constexpr int N = Model::NX, M = Model::NU;
+    constexpr int NR = Model::NX, M = Model::NU;      // real state / control sizes
+    constexpr int N = NR + (DU ? M : 0);              // size of the QP's state (z = [x; u_prev] if DU)
+    constexpr double INF = __builtin_huge_val();
     using L = BoxLayout<N, M>;
+    // augmented problem data, read straight from the caller's (A, B, c, Q, Qd, xd)
+    auto A_ = [&](int t, int i, int j) -> double {
+        if (i < NR) return j < NR ? a.At[((size_t)t * NR + i) * NR + j] : a.Bt[((size_t)t * NR + i) * M + (j - NR)];
+        return i == j ? 1.0 : 0.0;
+    };
+    auto B_ = [&](int t, int i, int j) -> double {
+        if (i < NR) return a.Bt[((size_t)t * NR + i) * M + j];
+        return (i - NR) == j ? 1.0 : 0.0;
+    };
+    auto c_ = [&](int t, int i) -> double { return i < NR ? a.ct[(size_t)t * NR + i] : 0.0; };
+    auto xd_ = [&](int t, int i) -> double { return i < NR ? a.xd[(size_t)t * NR + i] : 0.0; };
+    // bounds of the QP's state component i at time t, and of its control component j
+    auto zlo_ = [&](int t, int i) -> double {
+        if (i < NR) return a.xlo ? a.xlo[(size_t)t * a.sx + i] : -INF;
+        return (a.ulo && t >= 1) ? a.ulo[(size_t)(t - 1) * a.su + (i - NR)] : -INF;
+    };
+    auto zhi_ = [&](int t, int i) -> double {
+        if (i < NR) return a.xhi ? a.xhi[(size_t)t * a.sx + i] : INF;
+        return (a.uhi && t >= 1) ? a.uhi[(size_t)(t - 1) * a.su + (i - NR)] : INF;
+    };
+    auto vlo_ = [&](int t, int j) -> double {
+        if (DU) return a.dlo ? a.dlo[(size_t)t * a.sd + j] : -INF;
+        return a.ulo ? a.ulo[(size_t)t * a.su + j] : -INF;
+    };
+    auto vhi_ = [&](int t, int j) -> double {
+        if (DU) return a.dhi ? a.dhi[(size_t)t * a.sd + j] : INF;
+        return a.uhi ? a.uhi[(size_t)t * a.su + j] : INF;
+    };
     extern __shared__ double lds[];
     const int T = a.T, lane = threadIdx.x;
     double* F = lds;                                   // T records of L::S doubles
@@ -73,30 +124,28 @@ __global__ __launch_bounds__(64) void box_descent_kernel(BoxArgs a) {
     double* pv = PB + N * N;                           // p (N)
     double* gv = pv + N;                               // g (N)
     double* sv = gv + N;                               // s (M) .. padded to N
-    double* mxv = sv + N;                              // bounded masks / bounds
-    double* xlo = mxv + N;
-    double* xhi = xlo + N;
-    double* muv = xhi + N;                             // (M) each
-    double* ulo = muv + M;
-    double* uhi = ulo + M;
-    double* Hs = uhi + M;                              // M x M scratch (<= 16)
+    double* mxv = sv + N;                              // bounded masks (any finite bound at any t)
+    double* muv = mxv + N;                             // (M)
+    double* Hs = muv + M;                              // M x M scratch (<= 16)
 
     // ---- setup ------------------------------------------------------------------------
     if (lane < N) {
-        xlo[lane] = a.xlo[lane];
-        xhi[lane] = a.xhi[lane];
-        mxv[lane] = (isfinite(a.xlo[lane]) || isfinite(a.xhi[lane])) ? 1.0 : 0.0;
+        bool any = false;
+        for (int t = 1; t <= T; ++t) any = any || isfinite(zlo_(t, lane)) || isfinite(zhi_(t, lane));
+        mxv[lane] = any ? 1.0 : 0.0;
     }
     if (lane < M) {
-        ulo[lane] = a.ulo[lane];
-        uhi[lane] = a.uhi[lane];
-        muv[lane] = (isfinite(a.ulo[lane]) || isfinite(a.uhi[lane])) ? 1.0 : 0.0;
+        bool any = false;
+        for (int t = 0; t < T; ++t) any = any || isfinite(vlo_(t, lane)) || isfinite(vhi_(t, lane));
+        muv[lane] = any ? 1.0 : 0.0;
     }
     for (int q = lane; q < (T + 1) * N; q += 64) { wx[q] = 0.0; yx[q] = 0.0; zx[q] = 0.0; }
     for (int q = lane; q < T * M; q += 64) { wu[q] = 0.0; yu[q] = 0.0; zu[q] = 0.0; kk[q] = 0.0; }
     wave_sync();
     const double hr = 0.5 * a.rho;
-    auto qs = [&](const double* Qm, int i, int j) { return 0.5 * (Qm[i * N + j] + Qm[j * N + i]); };
+    auto qs = [&](const double* Qm, int i, int j) -> double {
+        return (i < NR && j < NR) ? 0.5 * (Qm[i * NR + j] + Qm[j * NR + i]) : 0.0;
+    };
     // P_T = Qd + rho/2 Mx ; qx_T = Qd xd_T
     for (int q = lane; q < N * N; q += 64) {
         int i = q / N, j = q % N;
@@ -104,7 +153,7 @@ __global__ __launch_bounds__(64) void box_descent_kernel(BoxArgs a) {
     }
     if (lane < N) {
         double s = 0.0;
-        for (int j = 0; j < N; ++j) s += qs(a.Qd, lane, j) * a.xd[(size_t)T * N + j];
+        for (int j = 0; j < N; ++j) s += qs(a.Qd, lane, j) * xd_(T, j);
         qxT[lane] = s;
     }
     wave_sync();
@@ -113,12 +162,12 @@ __global__ __launch_bounds__(64) void box_descent_kernel(BoxArgs a) {
     int bad = 0;
     for (int t = T - 1; t >= 0; --t) {
         double* rec = F + (size_t)t * L::S;
-        for (int q = lane; q < N * N; q += 64) Am[q] = a.At[(size_t)t * N * N + q];
-        for (int q = lane; q < N * M; q += 64) rec[L::oB + q] = a.Bt[(size_t)t * N * M + q];
+        for (int q = lane; q < N * N; q += 64) Am[q] = A_(t, q / N, q % N);
+        for (int q = lane; q < N * M; q += 64) rec[L::oB + q] = B_(t, q / M, q % M);
         if (lane < N) {
-            rec[L::oC + lane] = a.ct[(size_t)t * N + lane];
+            rec[L::oC + lane] = c_(t, lane);
             double s = 0.0;
-            for (int j = 0; j < N; ++j) s += qs(a.Q, lane, j) * a.xd[(size_t)t * N + j];
+            for (int j = 0; j < N; ++j) s += qs(a.Q, lane, j) * xd_(t, j);
             rec[L::oQx + lane] = s;
         }
         wave_sync();
@@ -241,20 +290,45 @@ __global__ __launch_bounds__(64) void box_descent_kernel(BoxArgs a) {
     }
 
     // ---- MPC loop: T tail re-solves, first control applied to the true dynamics ----------
-    double xr[N], ur[M], xn[N];
+    double xr[NR], ur[M], xn[NR], up[M];
 #pragma unroll
-    for (int i = 0; i < N; ++i) xr[i] = a.x0[i];
+    for (int i = 0; i < NR; ++i) xr[i] = a.x0[i];
+#pragma unroll
+    for (int j = 0; j < M; ++j) up[j] = 0.0;
     if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) a.x_new[i] = xr[i];
+        for (int i = 0; i < NR; ++i) a.x_new[i] = xr[i];
     }
+    double cost = 0.0;
+    auto quad = [&](const double* Wm_, const double* e, int K) -> double {   // e' sym(W) e, K = NR or M
+        double s = 0.0;
+        for (int i = 0; i < K; ++i)
+            for (int j = 0; j < K; ++j) s += e[i] * Wm_[i * K + j] * e[j];
+        return s;
+    };
     int it_max = 0, n_fail = 0;
     const double al = a.relax;
     for (int tau = 0; tau < T; ++tau) {
+        // the tail problem starts from the realised state; for DU its u_prev block is the
+        // realised actuated position x_tau[idx] (tv_lqr.py:99-100 at the tail's local t = 0)
+        double ub[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) ub[j] = 0.0;
+        if constexpr (DU) {
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                double v = xr[0];
+#pragma unroll
+                for (int i = 1; i < NR; ++i) v = (i == Model::u_into_x(j)) ? xr[i] : v;
+                ub[j] = v;
+            }
+        }
         if (lane < N) {
             double v = xr[0];
 #pragma unroll
-            for (int i = 1; i < N; ++i) v = (i == lane) ? xr[i] : v;
+            for (int i = 1; i < NR; ++i) v = (i == lane) ? xr[i] : v;
+#pragma unroll
+            for (int j = 0; j < M; ++j) v = (NR + j == lane) ? ub[j] : v;
             zx[(size_t)tau * N + lane] = v;
         }
         wave_sync();
@@ -307,10 +381,10 @@ __global__ __launch_bounds__(64) void box_descent_kernel(BoxArgs a) {
             // projection + dual update (x_tau is fixed: only t > tau), residuals
             double rp = 0.0, rd = 0.0;
             for (int q = (tau + 1) * N + lane; q < (T + 1) * N; q += 64) {
-                const int i = q % N;
+                const int i = q % N, t = q / N;
                 if (mxv[i] != 0.0) {
                     const double zr = al * zx[q] + (1.0 - al) * wx[q];
-                    const double wn = fmin(fmax(zr + yx[q], xlo[i]), xhi[i]);
+                    const double wn = fmin(fmax(zr + yx[q], zlo_(t, i)), zhi_(t, i));
                     rp = fmax(rp, fabs(zx[q] - wn));
                     rd = fmax(rd, fabs(wn - wx[q]));
                     yx[q] += zr - wn;
@@ -318,10 +392,10 @@ __global__ __launch_bounds__(64) void box_descent_kernel(BoxArgs a) {
                 }
             }
             for (int q = tau * M + lane; q < T * M; q += 64) {
-                const int j = q % M;
+                const int j = q % M, t = q / M;
                 if (muv[j] != 0.0) {
                     const double zr = al * zu[q] + (1.0 - al) * wu[q];
-                    const double wn = fmin(fmax(zr + yu[q], ulo[j]), uhi[j]);
+                    const double wn = fmin(fmax(zr + yu[q], vlo_(t, j)), vhi_(t, j));
                     rp = fmax(rp, fabs(zu[q] - wn));
                     rd = fmax(rd, fabs(wn - wu[q]));
                     yu[q] += zr - wn;
@@ -336,30 +410,55 @@ __global__ __launch_bounds__(64) void box_descent_kernel(BoxArgs a) {
         n_fail += conv ? 0 : 1;
         // first control of the tail solution (clipped), true dynamics step
 #pragma unroll
-        for (int j = 0; j < M; ++j) ur[j] = fmin(fmax(zu[(size_t)tau * M + j], ulo[j]), uhi[j]);
+        for (int j = 0; j < M; ++j) {
+            double v = fmin(fmax(zu[(size_t)tau * M + j], vlo_(tau, j)), vhi_(tau, j));
+            if constexpr (DU) v = fmin(fmax(ub[j] + v, zlo_(tau + 1, NR + j)), zhi_(tau + 1, NR + j));
+            ur[j] = v;
+        }
+        // running cost of the realised trajectory: IrsLqr.evaluate_cost (irs_lqr.py:121-137), or
+        // for DU IrsLqrQuasistatic.eval_cost (irs_lqr_quasistatic.py:153-194: R on u_t - u_{t-1})
+        {
+            double e[NR], dv[M];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) e[i] = xr[i] - a.xd[(size_t)tau * NR + i];
+#pragma unroll
+            for (int j = 0; j < M; ++j) dv[j] = DU ? ur[j] - (tau == 0 ? ub[j] : up[j]) : ur[j];
+            cost += quad(a.Q, e, NR) + quad(a.R, dv, M);
+        }
         Model::template step<double>(a.p, xr, ur, xn);
 #pragma unroll
-        for (int i = 0; i < N; ++i) xr[i] = xn[i];
+        for (int i = 0; i < NR; ++i) xr[i] = xn[i];
+#pragma unroll
+        for (int j = 0; j < M; ++j) up[j] = ur[j];
         if (lane == 0) {
 #pragma unroll
             for (int j = 0; j < M; ++j) a.u_new[(size_t)tau * M + j] = ur[j];
 #pragma unroll
-            for (int i = 0; i < N; ++i) a.x_new[(size_t)(tau + 1) * N + i] = xr[i];
+            for (int i = 0; i < NR; ++i) a.x_new[(size_t)(tau + 1) * NR + i] = xr[i];
         }
         wave_sync();
     }
-    if (lane == 0) { a.info[0] = bad; a.info[1] = it_max; a.info[2] = n_fail; }
+    {
+        double e[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) e[i] = xr[i] - a.xd[(size_t)T * NR + i];
+        cost += quad(DU ? a.Qd : a.Q, e, NR);       // terminal: Qd (quasistatic :160-168) vs Q (irs_lqr.py:135-136)
+    }
+    if (lane == 0) {
+        a.info[0] = bad; a.info[1] = it_max; a.info[2] = n_fail;
+        if (a.cost) a.cost[0] = cost;
+    }
 }
 
-template <class Model>
+template <class Model, bool DU>
 int launch_box(const BoxArgs& a, hipStream_t st) {
-    constexpr int N = Model::NX, M = Model::NU;
+    constexpr int N = Model::NX + (DU ? Model::NU : 0), M = Model::NU;
     const size_t bytes = BoxLayout<N, M>::doubles(a.T) * sizeof(double);
     if (bytes > 160 * 1024 - 512) {
         irs_set_error("irs_tvlqr_box_descent: horizon T=%d needs %zu bytes of LDS (max ~160 KB)", a.T, bytes);
         return IRS_ERR_UNSUPPORTED;
     }
-    auto kern = box_descent_kernel<Model>;
+    auto kern = box_descent_kernel<Model, DU>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) {
@@ -376,14 +475,19 @@ extern "C" {
 
 size_t irs_tvlqr_box_lds_bytes(int model, int T) {
     if (T <= 0) return 0;
-    switch (model) {
-        case IRS_MODEL_PENDULUM: return BoxLayout<2, 1>::doubles(T) * sizeof(double);
-        case IRS_MODEL_QUADROTOR: return BoxLayout<12, 4>::doubles(T) * sizeof(double);
-        case IRS_MODEL_BICYCLE: return BoxLayout<5, 2>::doubles(T) * sizeof(double);
-        case IRS_MODEL_THREE_CART: return BoxLayout<6, 2>::doubles(T) * sizeof(double);
-        case IRS_MODEL_PLANAR_HAND: return BoxLayout<7, 4>::doubles(T) * sizeof(double);
-    }
-    return 0;
+    size_t r = 0;
+    IRS_DISPATCH_MODEL(model, { r = BoxLayout<Model::NX, Model::NU>::doubles(T) * sizeof(double); });
+    return r;
+}
+
+size_t irs_quasistatic_box_lds_bytes(int model, int T) {
+    if (T <= 0) return 0;
+    size_t r = 0;
+    IRS_DISPATCH_MODEL(model, {
+        if constexpr (has_u_into_x<Model>::value)
+            r = BoxLayout<Model::NX + Model::NU, Model::NU>::doubles(T) * sizeof(double);
+    });
+    return r;
 }
 
 int irs_tvlqr_box_descent(int model, const double* params, int n_params, int T, const double* At,
@@ -399,11 +503,45 @@ int irs_tvlqr_box_descent(int model, const double* params, int n_params, int T, 
     int rc = irs_load_params(model, params, n_params, &a.p);
     if (rc != IRS_OK) return rc;
     a.At = At; a.Bt = Bt; a.ct = ct; a.Q = Q; a.Qd = Qd; a.R = R; a.xd = xd_trj; a.x0 = x0;
-    a.xlo = xlo; a.xhi = xhi; a.ulo = ulo; a.uhi = uhi;
+    a.xlo = xlo; a.xhi = xhi; a.ulo = ulo; a.uhi = uhi; a.dlo = nullptr; a.dhi = nullptr;
+    a.sx = 0; a.su = 0; a.sd = 0;
     a.x_new = x_new; a.u_new = u_new; a.cost = nullptr; a.info = info;
     a.alpha = alpha_R; a.rho = rho; a.relax = relax; a.eps = eps; a.T = T; a.max_iter = max_iter;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    IRS_DISPATCH_MODEL(model, { rc = launch_box<Model>(a, st); });
+    IRS_DISPATCH_MODEL(model, { rc = launch_box<Model, false>(a, st); });
+    if (rc != IRS_OK) return rc;
+    IRS_CHECK_LAUNCH();
+    return IRS_OK;
+}
+
+int irs_quasistatic_box_descent(int model, const double* params, int n_params, int T, const double* At,
+                                const double* Bt, const double* ct, const double* Q, const double* Qd,
+                                const double* R, const double* xd_trj, const double* x0,
+                                const double* x_lo, const double* x_hi, const double* u_lo,
+                                const double* u_hi, const double* du_lo, const double* du_hi,
+                                double rho, double relax, int max_iter, double eps, double* x_new,
+                                double* u_new, double* cost, int* info, void* stream) {
+    IRS_CHECK_ARG(T > 0 && At && Bt && ct && Q && Qd && R && xd_trj && x0 && x_new && u_new && info, "bad argument");
+    IRS_CHECK_ARG((x_lo == nullptr) == (x_hi == nullptr) && (u_lo == nullptr) == (u_hi == nullptr) &&
+                  (du_lo == nullptr) == (du_hi == nullptr), "give both sides of a bound or neither");
+    IRS_CHECK_ARG(rho > 0.0 && relax > 0.0 && relax < 2.0 && max_iter > 0 && eps > 0.0, "bad ADMM parameter");
+    BoxArgs a;
+    int rc = irs_load_params(model, params, n_params, &a.p);
+    if (rc != IRS_OK) return rc;
+    int n, m, np;
+    irs_model_info(model, &n, &m, &np);
+    a.At = At; a.Bt = Bt; a.ct = ct; a.Q = Q; a.Qd = Qd; a.R = R; a.xd = xd_trj; a.x0 = x0;
+    a.xlo = x_lo; a.xhi = x_hi; a.ulo = u_lo; a.uhi = u_hi; a.dlo = du_lo; a.dhi = du_hi;
+    a.sx = n; a.su = m; a.sd = m;
+    a.x_new = x_new; a.u_new = u_new; a.cost = cost; a.info = info;
+    a.alpha = 1.0;      // tv_lqr.py:107 adds du'R du as an expression: the full quadratic
+    a.rho = rho; a.relax = relax; a.eps = eps; a.T = T; a.max_iter = max_iter;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = IRS_ERR_UNSUPPORTED;
+    IRS_DISPATCH_MODEL(model, {
+        if constexpr (has_u_into_x<Model>::value) rc = launch_box<Model, true>(a, st);
+        else irs_set_error("irs_quasistatic_box_descent: model %d is not position controlled", model);
+    });
     if (rc != IRS_OK) return rc;
     IRS_CHECK_LAUNCH();
     return IRS_OK;

@@ -176,6 +176,34 @@ class DeviceModel:
               "irs_tvlqr_box_descent")
         return o
 
+    def quasistatic_descent_supported(self, T):
+        return 0 < self.lib.irs_quasistatic_box_lds_bytes(self.model_id, int(T)) <= self.BOX_LDS_LIMIT
+
+    def quasistatic_box_descent(self, At, Bt, ct, Q, Qd, R, xd_trj, x0, x_lo=None, x_hi=None, u_lo=None,
+                                u_hi=None, du_lo=None, du_hi=None, rho=10.0, relax=1.6, max_iter=5000,
+                                eps=1e-8, out=None):
+        """IrsLqrQuasistatic.local_descent after get_TV_matrices (irs_lqr_quasistatic.py:286-345) +
+        eval_cost.  Bounds are absolute per-time rows ((T+1,n) / (T,m)) or None.
+        Returns dict(x_new, u_new, cost, info[3])."""
+        T = At.shape[0]
+        dev = At.device
+        o = out
+        if o is None:
+            o = dict(x_new=torch.empty((T + 1, self.n), dtype=F64, device=dev),
+                     u_new=torch.empty((T, self.m), dtype=F64, device=dev),
+                     cost=torch.empty((1,), dtype=F64, device=dev),
+                     info=torch.empty((3,), dtype=torch.int32, device=dev))
+        for b, shape in ((x_lo, (T + 1, self.n)), (x_hi, (T + 1, self.n)), (u_lo, (T, self.m)),
+                         (u_hi, (T, self.m)), (du_lo, (T, self.m)), (du_hi, (T, self.m))):
+            assert b is None or tuple(b.shape) == shape, (tuple(b.shape), shape)
+        check(self.lib.irs_quasistatic_box_descent(
+            self.model_id, self._p, self._np, T, _ptr(At, F64), _ptr(Bt, F64), _ptr(ct, F64), _ptr(Q, F64),
+            _ptr(Qd, F64), _ptr(R, F64), _ptr(xd_trj, F64), _ptr(x0, F64), _ptr(x_lo, F64), _ptr(x_hi, F64),
+            _ptr(u_lo, F64), _ptr(u_hi, F64), _ptr(du_lo, F64), _ptr(du_hi, F64), float(rho), float(relax),
+            int(max_iter), float(eps), _ptr(o["x_new"], F64), _ptr(o["u_new"], F64), _ptr(o["cost"], F64),
+            o["info"].data_ptr(), _stream()), "irs_quasistatic_box_descent")
+        return o
+
     # ---- CEM baseline -------------------------------------------------------
     def cem_rollout_costs(self, u_cand, x0, Q, R, xd_trj):
         """costs (B) of the B candidate sequences u_cand (B,T,m): rollout + evaluate_cost each."""

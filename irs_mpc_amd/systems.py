@@ -1,4 +1,6 @@
 """Device-backed twins of the reference's analytic example plugins."""
+import numpy as np
+
 from ._lib import (MODEL_BICYCLE, MODEL_PENDULUM, MODEL_PLANAR_HAND, MODEL_QUADROTOR,
                    MODEL_THREE_CART)
 from .dynamical_system import DynamicalSystem
@@ -89,10 +91,56 @@ class PlanarHandDynamics(DynamicalSystem):
         self.base_x = 0.1
         self.pgs_iters = pgs_iters
 
+        # the bookkeeping QuasistaticDynamics derives from the plant (quasistatic_dynamics.py:22-28),
+        # keyed by model NAME here (the reference keys by ModelInstanceIndex)
+        self.models_unactuated = ["sphere"]
+        self.models_actuated = ["arm_left", "arm_right"]
+        self.models_all = self.models_unactuated + self.models_actuated
+        self.position_indices = {"sphere": np.array([0, 1, 2]), "arm_left": np.array([3, 4]),
+                                 "arm_right": np.array([5, 6])}
+        self.velocity_indices = self.position_indices
+
+    # ---- quasistatic_dynamics.py:57-130: vector <-> per-model dict helpers --------------
     def get_u_indices_into_x(self):
-        """quasistatic_dynamics.py:57-65."""
-        import numpy as np
-        return np.array([3, 4, 5, 6])
+        return np.concatenate([self.position_indices[m] for m in self.models_actuated])
+
+    def get_q_a_cmd_dict_from_u(self, u):
+        out, i = {}, 0
+        for m in self.models_actuated:
+            k = len(self.position_indices[m])
+            out[m] = u[i:i + k]
+            i += k
+        return out
+
+    def get_q_dict_from_x(self, x):
+        return {m: x[idx] for m, idx in self.position_indices.items()}
+
+    def get_x_from_q_dict(self, q_dict):
+        x = np.zeros(self.dim_x)
+        for m, idx in self.position_indices.items():
+            x[idx] = q_dict[m]
+        return x
+
+    def get_u_from_q_cmd_dict(self, q_cmd_dict):
+        return np.concatenate([np.asarray(q_cmd_dict[m], float) for m in self.models_actuated])
+
+    def get_Q_from_Q_dict(self, Q_dict):
+        Q = np.eye(self.dim_x)
+        for m, idx in self.velocity_indices.items():
+            Q[idx, idx] = Q_dict[m]
+        return Q
+
+    def get_R_from_R_dict(self, R_dict):
+        R = np.eye(self.dim_u)
+        i = 0
+        for m in self.models_actuated:
+            k = len(self.position_indices[m])
+            R[i:i + k, i:i + k] = np.diag(R_dict[m])
+            i += k
+        return R
+
+    def publish_trajectory(self, x_traj):
+        """quasistatic_dynamics.py:132-135 animates in meshcat; there is no visualiser here."""
 
     def device_params(self):
         return [self.h, self.g, self.mass, self.R, self.mu, self.kp[0], self.kp[1], self.l1, self.l2,

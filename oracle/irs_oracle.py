@@ -766,8 +766,15 @@ def zero_order_from_sums(system, x_trj, u_trj, sums):
 # carry that much solver noise; this restatement converges to ~1e-9.
 # --------------------------------------------------------------------------
 def _box_masks(lo, hi):
-    lo, hi = np.asarray(lo, float), np.asarray(hi, float)
-    return lo, hi, (np.isfinite(lo) | np.isfinite(hi)).astype(float)
+    """A component carries a rho term if it has a finite bound at ANY time (bounds may be one
+    row or one row per time step)."""
+    lo, hi = np.atleast_2d(np.asarray(lo, float)), np.atleast_2d(np.asarray(hi, float))
+    return lo, hi, (np.isfinite(lo) | np.isfinite(hi)).any(axis=0).astype(float)
+
+
+def _rows(b, rows, width):
+    """Bounds as one row per time step: (width,) is repeated, (rows,width) passes through."""
+    return np.broadcast_to(np.asarray(b, float), (rows, width))
 
 
 def tvlqr_box_factor(At, Bt, ct, Q, Qd, R, xlo, xhi, ulo, uhi, rho, alpha_R=0.5):
@@ -795,15 +802,15 @@ def tvlqr_box_factor(At, Bt, ct, Q, Qd, R, xlo, xhi, ulo, uhi, rho, alpha_R=0.5)
 
 
 def tvlqr_box_solve(F, At, Bt, ct, Q, Qd, xd, x_start, t0, xlo, xhi, ulo, uhi, state=None,
-                    max_iter=2000, eps=1e-9):
+                    max_iter=2000, eps=1e-9, relax=1.0):
     """ADMM for the tail problem t0..T from the fixed state x_start.  `state` = (wx, yx,
     wu, yu) warm start (arrays over the FULL horizon).  Returns x (T+1,n), u (T,m) (rows
     < t0 untouched/zero), state, iterations."""
     T, n = At.shape[0], Q.shape[0]
     m = Bt.shape[2]
     rho, mx, mu = F["rho"], F["mx"], F["mu"]
-    xlo, xhi = np.asarray(xlo, float), np.asarray(xhi, float)
-    ulo, uhi = np.asarray(ulo, float), np.asarray(uhi, float)
+    xlo, xhi = _rows(xlo, T + 1, n), _rows(xhi, T + 1, n)       # row t bounds x_t
+    ulo, uhi = _rows(ulo, T, m), _rows(uhi, T, m)               # row t bounds u_t
     if state is None:
         state = (np.zeros((T + 1, n)), np.zeros((T + 1, n)), np.zeros((T, m)), np.zeros((T, m)))
     wx, yx, wu, yu = state
@@ -824,12 +831,14 @@ def tvlqr_box_solve(F, At, Bt, ct, Q, Qd, xd, x_start, t0, xlo, xhi, ulo, uhi, s
             zu[t] = F["K"][t] @ zx[t] + k[t]
             zx[t + 1] = At[t] @ zx[t] + Bt[t] @ zu[t] + ct[t]
         # box projection + dual update (x_t0 is fixed, not a variable)
-        wxn = np.clip(zx[t0 + 1:] + yx[t0 + 1:], xlo, xhi)
-        wun = np.clip(zu[t0:] + yu[t0:], ulo, uhi)
+        zrx = relax * zx[t0 + 1:] + (1.0 - relax) * wx[t0 + 1:]      # over-relaxation (OSQP's alpha)
+        zru = relax * zu[t0:] + (1.0 - relax) * wu[t0:]
+        wxn = np.clip(zrx + yx[t0 + 1:], xlo[t0 + 1:], xhi[t0 + 1:])
+        wun = np.clip(zru + yu[t0:], ulo[t0:], uhi[t0:])
         rp = max(np.abs(mx * (zx[t0 + 1:] - wxn)).max(), np.abs(mu * (zu[t0:] - wun)).max())
         rd = rho * max(np.abs(mx * (wxn - wx[t0 + 1:])).max(), np.abs(mu * (wun - wu[t0:])).max())
-        yx[t0 + 1:] += mx * (zx[t0 + 1:] - wxn)
-        yu[t0:] += mu * (zu[t0:] - wun)
+        yx[t0 + 1:] += mx * (zrx - wxn)
+        yu[t0:] += mu * (zru - wun)
         wx[t0 + 1:], wu[t0:] = wxn, wun
         if max(rp, rd) < eps:
             break
@@ -846,11 +855,12 @@ def local_descent_box(system, At, Bt, ct, Q, Qd, R, x0, xd_trj, xlo, xhi, ulo, u
     x_new, u_new = np.zeros((T + 1, n)), np.zeros((T, m))
     x_new[0] = x0
     state, iters = None, []
+    ulo_t, uhi_t = _rows(ulo, T, m), _rows(uhi, T, m)
     for t in range(T):
         zx, zu, state, it = tvlqr_box_solve(F, At, Bt, ct, Q, Qd, xd_trj, x_new[t], t, xlo, xhi, ulo, uhi,
                                             state, max_iter, eps)
         iters.append(it)
-        u_new[t] = np.clip(zu[t], ulo, uhi)
+        u_new[t] = np.clip(zu[t], ulo_t[t], uhi_t[t])
         x_new[t + 1] = system.dynamics(x_new[t], u_new[t])
     return x_new, u_new, iters
 
@@ -866,8 +876,8 @@ def qp_box_kkt_residuals(At, Bt, ct, Q, Qd, R, x0, xd, xlo, xhi, ulo, uhi, x, u,
     solution."""
     T, n = At.shape[0], Q.shape[0]
     m = R.shape[0]
-    xlo, xhi = np.broadcast_to(np.asarray(xlo, float), (n,)), np.broadcast_to(np.asarray(xhi, float), (n,))
-    ulo, uhi = np.broadcast_to(np.asarray(ulo, float), (m,)), np.broadcast_to(np.asarray(uhi, float), (m,))
+    xlo, xhi = _rows(xlo, T + 1, n), _rows(xhi, T + 1, n)
+    ulo, uhi = _rows(ulo, T, m), _rows(uhi, T, m)
     nz = T * n + T * m
     ix = lambda t: slice((t - 1) * n, t * n)                 # x_t, t = 1..T
     iu = lambda t: slice(T * n + t * m, T * n + (t + 1) * m)
@@ -889,8 +899,8 @@ def qp_box_kkt_residuals(At, Bt, ct, Q, Qd, R, x0, xd, xlo, xhi, ulo, uhi, x, u,
         E[r, ix(t + 1)] = -np.eye(n)
         b[r] -= ct[t]
     z = np.concatenate([x[1:].ravel(), u.ravel()])
-    lo = np.concatenate([np.tile(xlo, T), np.tile(ulo, T)])
-    hi = np.concatenate([np.tile(xhi, T), np.tile(uhi, T)])
+    lo = np.concatenate([xlo[1:].ravel(), ulo.ravel()])
+    hi = np.concatenate([xhi[1:].ravel(), uhi.ravel()])
     r_dyn = np.abs(E @ z - b).max()
     r_box = max(0.0, (lo - z).max(), (z - hi).max())
     at_hi, at_lo = z >= hi - tol, z <= lo + tol
@@ -906,3 +916,82 @@ def qp_box_kkt_residuals(At, Bt, ct, Q, Qd, R, x0, xd, xlo, xhi, ulo, uhi, x, u,
         elif at_lo[i] and not at_hi[i]:
             sign_bad = max(sign_bad, mu[j])
     return r_dyn, r_box, r_stat, sign_bad
+
+
+# --------------------------------------------------------------------------
+# IrsLqrQuasistatic (irs_lqr/irs_lqr_quasistatic.py): position-controlled systems
+# --------------------------------------------------------------------------
+def quasistatic_augment(At, Bt, ct, Q, Qd, xd_trj):
+    """solve_tvlqr with indices_u_into_x (irs_lqr/tv_lqr.py:96-108) penalises du_t = u_t - u_{t-1}
+    (du_0 = u_0 - x_0[idx]).  With z = [x; u_prev] and v = du it is a plain TV-LQR:
+        z+ = [[A, B], [0, I]] z + [B; I] v + [c; 0],   cost (x-xd)'Q(x-xd) + v'R v."""
+    T, n, m = Bt.shape
+    N = n + m
+    Ab, Bb, cb = np.zeros((T, N, N)), np.zeros((T, N, m)), np.zeros((T, N))
+    Ab[:, :n, :n], Ab[:, :n, n:], Ab[:, n:, n:] = At, Bt, np.eye(m)
+    Bb[:, :n], Bb[:, n:] = Bt, np.eye(m)
+    cb[:, :n] = ct
+    Qb, Qdb = np.zeros((N, N)), np.zeros((N, N))
+    Qb[:n, :n], Qdb[:n, :n] = Q, Qd
+    xdb = np.hstack([xd_trj, np.zeros((xd_trj.shape[0], m))])
+    return Ab, Bb, cb, Qb, Qdb, xdb
+
+
+def quasistatic_bounds(x_trj, idx, x_bounds_abs=None, u_bounds_abs=None, u_bounds_rel=None):
+    """irs_lqr_quasistatic.py:303-325: abs bounds are trust-region OFFSETS around the nominal
+    trajectory (u's around the nominal actuated positions x_trj[:-1, idx]), rel bounds limit
+    u_t - u_{t-1}.  Returns absolute per-time rows (x_lo, x_hi (T+1,n); u_lo, u_hi, du_lo, du_hi
+    (T,m)), +-inf where absent."""
+    T, n, m = x_trj.shape[0] - 1, x_trj.shape[1], len(idx)
+    inf = np.inf
+    x_lo, x_hi = np.full((T + 1, n), -inf), np.full((T + 1, n), inf)
+    u_lo, u_hi = np.full((T, m), -inf), np.full((T, m), inf)
+    du_lo, du_hi = np.full((T, m), -inf), np.full((T, m), inf)
+    if x_bounds_abs is not None:
+        x_lo, x_hi = x_trj + x_bounds_abs[0], x_trj + x_bounds_abs[1]
+    if u_bounds_abs is not None:
+        u_lo, u_hi = x_trj[:-1, idx] + u_bounds_abs[0], x_trj[:-1, idx] + u_bounds_abs[1]
+    if u_bounds_rel is not None:
+        du_lo = np.tile(np.asarray(u_bounds_rel[0], float), (T, 1))
+        du_hi = np.tile(np.asarray(u_bounds_rel[1], float), (T, 1))
+    return x_lo, x_hi, u_lo, u_hi, du_lo, du_hi
+
+
+def eval_cost_quasistatic(x_trj, u_trj, xd_trj, Q, Qd, R, idx):
+    """irs_lqr_quasistatic.py:153-194: state error with Q (terminal: Qd, unlike IrsLqr), input cost
+    on u_t - u_{t-1} with du_0 = u_0 - x_0[idx]."""
+    T = u_trj.shape[0]
+    cost = 0.0
+    for t in range(T):
+        e = x_trj[t] - xd_trj[t]
+        du = u_trj[t] - (x_trj[0, idx] if t == 0 else u_trj[t - 1])
+        cost += e.dot(Q).dot(e) + du.dot(R).dot(du)
+    e = x_trj[T] - xd_trj[T]
+    return cost + e.dot(Qd).dot(e)
+
+
+def local_descent_quasistatic(system, At, Bt, ct, Q, Qd, R, x0, xd_trj, x_lo, x_hi, u_lo, u_hi, du_lo, du_hi,
+                              rho=1.0, max_iter=4000, eps=1e-9, relax=1.0):
+    """irs_lqr_quasistatic.py:326-345: for every t the tail QP is re-solved from the realised
+    state -- whose local du_0 is measured from the realised actuated position x_t[idx]
+    (tv_lqr.py:99-100) -- and its first control goes to the TRUE dynamics.  Bounds as returned by
+    quasistatic_bounds.  The QPs are solved by the box ADMM above on the augmented problem."""
+    T, n, m = Bt.shape
+    idx = system.indices_u_into_x
+    Ab, Bb, cb, Qb, Qdb, xdb = quasistatic_augment(At, Bt, ct, Q, Qd, xd_trj)
+    # z_t = [x_t; u_{t-1}]: the u bounds at time t sit on the u_prev block of z_{t+1}
+    zlo = np.hstack([x_lo, np.vstack([np.full((1, m), -np.inf), u_lo])])
+    zhi = np.hstack([x_hi, np.vstack([np.full((1, m), np.inf), u_hi])])
+    F = tvlqr_box_factor(Ab, Bb, cb, Qb, Qdb, R, zlo, zhi, du_lo, du_hi, rho, alpha_R=1.0)
+    x_new, u_new = np.zeros((T + 1, n)), np.zeros((T, m))
+    x_new[0] = x0
+    state, iters = None, []
+    for t in range(T):
+        z_t = np.concatenate([x_new[t], x_new[t][idx]])
+        zx, zu, state, it = tvlqr_box_solve(F, Ab, Bb, cb, Qb, Qdb, xdb, z_t, t, zlo, zhi, du_lo, du_hi,
+                                            state, max_iter, eps, relax)
+        iters.append(it)
+        v = np.clip(zu[t], du_lo[t], du_hi[t])
+        u_new[t] = np.clip(z_t[n:] + v, u_lo[t], u_hi[t])
+        x_new[t + 1] = system.dynamics(x_new[t], u_new[t])
+    return x_new, u_new, iters

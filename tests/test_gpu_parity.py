@@ -781,3 +781,91 @@ def test_planar_hand_descent_runs(amd):
     xo, uo = orc.closed_loop_rollout(sys_o, K.cpu().numpy(), k.cpu().numpy(), x0)
     np.testing.assert_allclose(x_new.cpu().numpy(), xo, rtol=0, atol=1e-8)
     np.testing.assert_allclose(float(cost.item()), orc.evaluate_cost(xo, uo, xd, Q, R), rtol=1e-9)
+
+
+def _hand_problem(amd, T, N, seed):
+    sys_d, sys_o, x0, _ = _hand_setup(amd, T)
+    u_trj = np.tile(x0[3:], (T, 1))
+    x_trj = orc.rollout(sys_o, x0, u_trj)
+    du = (np.random.default_rng(seed).normal(size=(T, N, 4)) * 0.1).astype(np.float32)
+    At, Bt, ct = orc.zero_order_B_decoupled(sys_o, x_trj, u_trj, du.astype(np.float64))
+    q = np.array([1e-3, 1e-3, 10, 1e-3, 1e-3, 1e-3, 1e-3])          # run_planar_hand.py:113-131
+    Q, Qd, R = np.diag(q), np.diag(100 * q), 5.0 * np.eye(4)
+    xd = np.tile(x0 + np.array([0.3, -0.1, 0.5, 0, 0, 0, 0]), (T + 1, 1))
+    return sys_d, sys_o, x0, u_trj, x_trj, du, (At, Bt, ct), (Q, Qd, R, xd)
+
+
+@pytest.mark.parametrize("bounds", ["abs", "rel", "abs+rel+x"])
+def test_quasistatic_box_descent_vs_oracle(amd, bounds):
+    """IrsLqrQuasistatic.local_descent after get_TV_matrices (irs_lqr_quasistatic.py:286-345): du cost,
+    per-time trust-region bounds, T re-solved tail QPs, true (contact) dynamics in the loop."""
+    from irs_mpc_amd import device as dev
+    T = 8
+    sys_d, sys_o, x0, u_trj, x_trj, _, (At, Bt, ct), (Q, Qd, R, xd) = _hand_problem(amd, T, 400, 21)
+    idx = sys_o.indices_u_into_x
+    ub = np.array([-np.ones(4) * 0.05, np.ones(4) * 0.05]) if "abs" in bounds else None     # run_planar_hand.py:138
+    rb = np.array([-np.ones(4) * 0.03, np.ones(4) * 0.03]) if "rel" in bounds else None
+    xb = np.array([-np.ones(7) * 0.04, np.ones(7) * 0.04]) if "x" in bounds else None
+    rows = orc.quasistatic_bounds(x_trj, idx, xb, ub, rb)
+    xo, uo, iters = orc.local_descent_quasistatic(sys_o, At, Bt, ct, Q, Qd, R, x0, xd, *rows, rho=100.0,
+                                                  max_iter=40000, eps=1e-10, relax=1.6)
+    assert max(iters) < 40000
+    dm = sys_d.dm()
+    rows_d = [dev.to_dev(r) if np.isfinite(r).any() else None for r in rows]
+    o = dm.quasistatic_box_descent(*[dev.to_dev(a) for a in (At, Bt, ct, Q, Qd, R, xd, x0)], *rows_d,
+                                   rho=100.0, relax=1.6, max_iter=40000, eps=1e-10)
+    info = o["info"].cpu().numpy()
+    assert info[0] == 0 and info[2] == 0, info
+    np.testing.assert_allclose(o["u_new"].cpu().numpy(), uo, rtol=0, atol=2e-7)
+    np.testing.assert_allclose(o["x_new"].cpu().numpy(), xo, rtol=0, atol=2e-7)
+    np.testing.assert_allclose(float(o["cost"].item()), orc.eval_cost_quasistatic(xo, uo, xd, Q, Qd, R, idx),
+                               rtol=1e-7)
+    # the bounds bind (otherwise this would not test the QP)
+    un = o["u_new"].cpu().numpy()
+    if "abs" in bounds:
+        assert np.isclose(np.abs(un - x_trj[:-1, idx]).max(), 0.05, atol=1e-7)
+    else:
+        # every tail's first du is measured from the REALISED actuated position (tv_lqr.py:99-100)
+        d = un - o["x_new"].cpu().numpy()[:-1, idx]
+        assert np.isclose(np.abs(d).max(), 0.03, atol=1e-7)
+
+
+def test_irs_lqr_quasistatic_host_twin(amd):
+    """IrsLqrQuasistatic end to end (irs_lqr_quasistatic.py:44-390): identical np.random seeds give the
+    oracle's first descent; the cost bookkeeping matches eval_cost; iterate() lowers the cost."""
+    T, N = 8, 300
+    sys_d, sys_o, x0, u_trj, _, _, _, (Q, Qd, R, xd) = _hand_problem(amd, T, 4, 0)
+    p = amd.IrsLqrQuasistaticParameters()
+    q_dict = {"sphere": np.array([1e-3, 1e-3, 10.0]), "arm_left": np.array([1e-3, 1e-3]),
+              "arm_right": np.array([1e-3, 1e-3])}
+    p.Q_dict = q_dict
+    p.Qd_dict = {k: 100 * v for k, v in q_dict.items()}
+    p.R_dict = {"arm_left": 5 * np.ones(2), "arm_right": 5 * np.ones(2)}
+    p.x0, p.x_trj_d, p.u_trj_0, p.T = x0, xd, u_trj, T
+    p.u_bounds_abs = np.array([-np.ones(4) * 0.05, np.ones(4) * 0.05])
+    p.sampling = lambda u_initial, it: u_initial / (it ** 0.8)          # run_planar_hand.py:142-143
+    p.std_u_initial = np.ones(4) * 0.1
+    p.num_samples = N
+    p.publish_every_iteration = False
+    p.qp_rho, p.qp_max_iter, p.qp_eps = 100.0, 40000, 1e-10
+    sol = amd.IrsLqrQuasistatic(sys_d, p)
+    sol.verbose = False
+    idx = sys_o.indices_u_into_x
+    np.testing.assert_allclose(sum(sol.eval_cost(sol.x_trj, sol.u_trj)),
+                               orc.eval_cost_quasistatic(sol.x_trj, sol.u_trj, xd, Q, Qd, R, idx), rtol=1e-12)
+    # first descent from identical seeds
+    np.random.seed(7)
+    xn, un = sol.local_descent(sol.x_trj, sol.u_trj)
+    np.random.seed(7)
+    du = np.stack([np.random.normal(0, p.std_u_initial, size=[N, 4]) for _ in range(T)]).astype(np.float32)
+    At, Bt, ct = orc.zero_order_B_decoupled(sys_o, sol.x_trj, sol.u_trj, du.astype(np.float64))
+    rows = orc.quasistatic_bounds(sol.x_trj, idx, None, p.u_bounds_abs, None)
+    xo, uo, _ = orc.local_descent_quasistatic(sys_o, At, Bt, ct, Q, Qd, R, x0, xd, *rows, rho=100.0,
+                                              max_iter=40000, eps=1e-10, relax=1.6)
+    # B is fitted from f32 one-step evaluations on the device: the QP data differ at the 1e-4 level
+    np.testing.assert_allclose(un, uo, rtol=0, atol=5e-3)
+    np.testing.assert_allclose(xn, xo, rtol=0, atol=5e-3)
+    c0 = sol.cost
+    sol.iterate(3)
+    assert len(sol.cost_all_list) == 5 and sol.cost_best < c0
+    assert sol.x_trj_best.shape == (T + 1, 7) and sol.current_iter == 4

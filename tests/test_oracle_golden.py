@@ -349,3 +349,39 @@ def test_planar_hand_symmetric_grasp_stays_symmetric():
     assert abs(x[0]) < 1e-9 and abs(x[2]) < 1e-9
     np.testing.assert_allclose(x[3:5], -x[5:7], atol=1e-9)
     assert 0.30 < x[1] < 0.35                   # resting in the cradle, not through it
+
+
+def test_quasistatic_tail_qp_kkt_certificate():
+    """The du-cost, per-time-bounded tail QP of IrsLqrQuasistatic.local_descent
+    (irs_lqr_quasistatic.py:326-345 -> tv_lqr.py:30-137), solved by the box ADMM on the
+    [x; u_prev] augmentation, satisfies the ORIGINAL QP's KKT conditions."""
+    T, N = 6, 300
+    o = orc.PlanarHandOracle(0.1)
+    x0 = _hand_x0()
+    for _ in range(4):
+        x0 = o.dynamics(x0, _hand_x0()[3:])
+    u_trj = np.tile(x0[3:], (T, 1))
+    x_trj = orc.rollout(o, x0, u_trj)
+    du = 0.1 * np.random.default_rng(5).normal(size=(T, N, 4))
+    At, Bt, ct = orc.zero_order_B_decoupled(o, x_trj, u_trj, du)
+    q = np.array([1e-3, 1e-3, 10, 1e-3, 1e-3, 1e-3, 1e-3])
+    Q, Qd, R = np.diag(q), np.diag(100 * q), 5 * np.eye(4)
+    xd = np.tile(x0 + np.array([0.3, -0.1, 0.5, 0, 0, 0, 0]), (T + 1, 1))
+    idx, m = o.indices_u_into_x, 4
+    rows = orc.quasistatic_bounds(x_trj, idx, None, np.array([-np.ones(4) * 0.05, np.ones(4) * 0.05]),
+                                  np.array([-np.ones(4) * 0.03, np.ones(4) * 0.03]))
+    Ab, Bb, cb, Qb, Qdb, xdb = orc.quasistatic_augment(At, Bt, ct, Q, Qd, xd)
+    zlo = np.hstack([rows[0], np.vstack([np.full((1, m), -np.inf), rows[2]])])
+    zhi = np.hstack([rows[1], np.vstack([np.full((1, m), np.inf), rows[3]])])
+    F = orc.tvlqr_box_factor(Ab, Bb, cb, Qb, Qdb, R, zlo, zhi, rows[4], rows[5], 100.0, alpha_R=1.0)
+    z0 = np.concatenate([x0, x0[idx]])
+    zx, zu, _, it = orc.tvlqr_box_solve(F, Ab, Bb, cb, Qb, Qdb, xdb, z0, 0, zlo, zhi, rows[4], rows[5], None,
+                                        40000, 1e-11, 1.6)
+    assert it < 40000
+    r_dyn, r_box, r_stat, sign_bad = orc.qp_box_kkt_residuals(Ab, Bb, cb, Qb, Qdb, R, z0, xdb, zlo, zhi,
+                                                              rows[4], rows[5], zx, zu, alpha_R=1.0)
+    assert r_dyn < 1e-10 and r_box < 1e-9 and r_stat < 1e-7 and sign_bad < 1e-7
+    # the augmentation reproduces the reference's variables: u_t = u_prev block one step later
+    u = zx[1:, 7:]
+    np.testing.assert_allclose(np.diff(np.vstack([x0[idx][None], u]), axis=0), zu, atol=1e-12)
+    assert np.abs(zu).max() > 0.03 - 1e-9 and np.abs(u - x_trj[:-1, idx]).max() > 0.05 - 1e-9
