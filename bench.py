@@ -217,18 +217,38 @@ def main():
                 tv["At"], tv["Bt"], tv["ct"], tv["info"] = dm.smooth_finalize(MODE, n_total, x_trj, u_trj, plan.sums)
 
         smooth_step()
-        descent = dev.DescentPlan(dm, tv["At"], tv["Bt"], tv["ct"], Q, Qd, R, xd, x0)
+        if w.name == "planar_hand":
+            # IrsLqrQuasistatic.local_descent (irs_lqr_quasistatic.py:286-345) as run_planar_hand.py
+            # sets it up: du cost, trust region u_bounds_abs = +-0.5 h around the nominal actuated
+            # positions (:138-139), T re-solved tail QPs, contact dynamics in the loop; one launch
+            nom = x_trj[:-1].index_select(1, torch.tensor([3, 4, 5, 6], device=x_trj.device))
+            u_lo, u_hi = (nom - 0.5 * w.system.h).contiguous(), (nom + 0.5 * w.system.h).contiguous()
+            qs_out = {}
+
+            def descent_run():
+                qs_out["o"] = dm.quasistatic_box_descent(tv["At"], tv["Bt"], tv["ct"], Q, Qd, R, xd, x0,
+                                                         u_lo=u_lo, u_hi=u_hi, solver=0, max_iter=2000,
+                                                         eps=1e-9, out=qs_out.get("o"))
+        else:
+            descent = dev.DescentPlan(dm, tv["At"], tv["Bt"], tv["ct"], Q, Qd, R, xd, x0)
+
+            def descent_run():
+                if world > 1:       # finalize allocated fresh outputs
+                    c = descent.call
+                    c.At, c.Bt, c.ct = tv["At"].data_ptr(), tv["Bt"].data_ptr(), tv["ct"].data_ptr()
+                descent.run(stream)
 
         def ilqr_step():
             smooth_step()
-            if world > 1:       # finalize allocated fresh outputs
-                c = descent.call
-                c.At, c.Bt, c.ct = tv["At"].data_ptr(), tv["Bt"].data_ptr(), tv["ct"].data_ptr()
-            descent.run(stream)
+            descent_run()
 
         el, ev_ms = timed(smooth_step, steps, warmup)
-        el_it, _ = timed(ilqr_step, max(1, steps // 4), max(1, warmup // 4))
-        el_it *= steps / max(1, steps // 4)
+        it_steps = max(1, steps // (4 if w.name == "pendulum" else 20))
+        el_it, _ = timed(ilqr_step, it_steps, max(1, it_steps // 10))
+        el_it *= steps / it_steps
+        if w.name == "planar_hand":
+            qi = qs_out["o"]["info"].cpu().numpy()
+            assert qi[0] == 0 and qi[2] == 0, "bounded TV-LQR did not converge: %s" % qi
         # Kernel time of the sample pass: HIP events recorded on the stream the kernel is
         # launched on (torch's current stream is the one handed to the C ABI), bracketing
         # `steps` launches of the timed region when the step is a single launch, otherwise
@@ -293,6 +313,10 @@ def main():
                    "parallelism": "samples sharded over %d GPU(s), 1 all-reduce of (T,P) f64 per step" % world},
         "ilqr_iters_per_s": args.steps / el_it,
         "ms_per_ilqr_iter": 1e3 * el_it / args.steps,
+        "ilqr_iter": ("smoothing launch + IrsLqrQuasistatic.local_descent (du cost, u_bounds_abs = +-0.5h trust "
+                      "region, T re-solved tail QPs by the active-set solver, contact dynamics in the loop)"
+                      if w.name == "planar_hand" else
+                      "smoothing launch + Riccati + closed-loop rollout + cost (bounds inactive)"),
         "roofline": roofline(w, N, k_mean, nm),
     }
     if args.sweep and world == 1:

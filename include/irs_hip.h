@@ -246,7 +246,16 @@ size_t irs_tvlqr_box_lds_bytes(int model, int T);
  *   u_lo,u_hi (T,m)  : ABSOLUTE bounds on u_t    reference's trust-region offsets, :303-314)
  *   du_lo,du_hi (T,m): bounds on u_t - u_{t-1}  (u_bounds_rel, :321-325)
  * x_bound_rel is not supported ("should be rarely used", :315-319).
- * cost (1) DEV (may be NULL); info (3) as irs_tvlqr_box_descent.                              */
+ * solver: 1 = the ADMM of irs_tvlqr_box_descent on the augmented problem (any combination of
+ *   bounds; rho, relax, max_iter, eps as there);
+ *   2 = exact active-set method (primal-dual active set with a primal active-set safeguard) on the
+ *   control-box form of the QP: needs x_lo == NULL and at most ONE of the u / du pairs (every
+ *   example of the reference); the active set and the backward sweep are carried from tail to
+ *   tail; eps = tolerance on bounds and multipliers, max_iter = cap on safeguard iterations per
+ *   tail, rho/relax unused;
+ *   0 = 2 where it applies and fits LDS, else 1.
+ * cost (1) DEV (may be NULL); info (3): [0] t+1 of a non-PD Hessian, [1] most iterations any tail
+ * needed, [2] number of tails that did not converge.                                          */
 int irs_quasistatic_box_descent(int model, const double *params, int n_params, int T,
                                 const double *At, const double *Bt, const double *ct,
                                 const double *Q, const double *Qd, const double *R,
@@ -254,9 +263,9 @@ int irs_quasistatic_box_descent(int model, const double *params, int n_params, i
                                 const double *x_lo, const double *x_hi,
                                 const double *u_lo, const double *u_hi,
                                 const double *du_lo, const double *du_hi,
-                                double rho, double relax, int max_iter, double eps,
+                                int solver, double rho, double relax, int max_iter, double eps,
                                 double *x_new, double *u_new, double *cost, int *info, void *stream);
-size_t irs_quasistatic_box_lds_bytes(int model, int T);
+size_t irs_quasistatic_box_lds_bytes(int model, int T, int solver);
 
 /* ---- Cross-entropy-method baseline (irs_lqr/cem.py:151-184) -------------------- */
 

@@ -24,9 +24,7 @@
 // matrices are never materialised: accessors below read (A,B,c) directly.
 //
 // One wave, f64, everything in (dynamic) LDS: a latency-bound chain like the Riccati pass.
-#include <type_traits>
-
-#include "irs_common.hpp"
+#include "boxqp.hpp"
 
 namespace {
 
@@ -41,21 +39,6 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
-struct BoxArgs {
-    ModelParams p;
-    const double *At, *Bt, *ct, *Q, *Qd, *R, *xd, *x0;
-    // bounds: row t at ptr + t * stride (stride 0 = one constant row); null = unbounded; +-inf ok
-    const double *xlo, *xhi;                 // on x_t, t = 0..T   (row 0 unused: x_0 is fixed)
-    const double *ulo, *uhi;                 // on u_t, t = 0..T-1
-    const double *dlo, *dhi;                 // DU only: on u_t - u_{t-1}
-    int sx, su, sd;
-    double *x_new, *u_new, *cost;            // cost may be null
-    int* info;                               // [0] Hessian not PD at t+1, [1] max ADMM iterations used,
-                                             // [2] number of tail problems that hit max_iter
-    double alpha, rho, relax, eps;
-    int T, max_iter;
-};
-
 template <int N, int M>
 struct BoxLayout {
     // per-timestep factor record
@@ -66,11 +49,6 @@ struct BoxLayout {
         return (size_t)T * S + N + 3 * (size_t)(T + 1) * N + 4 * (size_t)T * M + 4 * N * N + 8 * N + 4 * M + 64;
     }
 };
-
-template <class M, class = void>
-struct has_u_into_x : std::false_type {};
-template <class M>
-struct has_u_into_x<M, std::void_t<decltype(M::u_into_x(0))>> : std::true_type {};
 
 template <class Model, bool DU>
 __global__ __launch_bounds__(64) void box_descent_kernel(BoxArgs a) {
@@ -480,8 +458,9 @@ size_t irs_tvlqr_box_lds_bytes(int model, int T) {
     return r;
 }
 
-size_t irs_quasistatic_box_lds_bytes(int model, int T) {
+size_t irs_quasistatic_box_lds_bytes(int model, int T, int solver) {
     if (T <= 0) return 0;
+    if (solver == 2) return irs_ctrlbox_lds_bytes(model, T);
     size_t r = 0;
     IRS_DISPATCH_MODEL(model, {
         if constexpr (has_u_into_x<Model>::value)
@@ -519,9 +498,10 @@ int irs_quasistatic_box_descent(int model, const double* params, int n_params, i
                                 const double* R, const double* xd_trj, const double* x0,
                                 const double* x_lo, const double* x_hi, const double* u_lo,
                                 const double* u_hi, const double* du_lo, const double* du_hi,
-                                double rho, double relax, int max_iter, double eps, double* x_new,
-                                double* u_new, double* cost, int* info, void* stream) {
+                                int solver, double rho, double relax, int max_iter, double eps,
+                                double* x_new, double* u_new, double* cost, int* info, void* stream) {
     IRS_CHECK_ARG(T > 0 && At && Bt && ct && Q && Qd && R && xd_trj && x0 && x_new && u_new && info, "bad argument");
+    IRS_CHECK_ARG(solver >= 0 && solver <= 2, "solver must be 0 (auto), 1 (ADMM) or 2 (active set)");
     IRS_CHECK_ARG((x_lo == nullptr) == (x_hi == nullptr) && (u_lo == nullptr) == (u_hi == nullptr) &&
                   (du_lo == nullptr) == (du_hi == nullptr), "give both sides of a bound or neither");
     IRS_CHECK_ARG(rho > 0.0 && relax > 0.0 && relax < 2.0 && max_iter > 0 && eps > 0.0, "bad ADMM parameter");
@@ -537,6 +517,19 @@ int irs_quasistatic_box_descent(int model, const double* params, int n_params, i
     a.alpha = 1.0;      // tv_lqr.py:107 adds du'R du as an expression: the full quadratic
     a.rho = rho; a.relax = relax; a.eps = eps; a.T = T; a.max_iter = max_iter;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // one control box (or none) and no state bounds: the exact active-set solver applies
+    const bool one_box = x_lo == nullptr && !(u_lo != nullptr && du_lo != nullptr);
+    if (solver == 2 && !one_box) {
+        irs_set_error("irs_quasistatic_box_descent: the active-set solver handles ONE of u / du bounds and no x bounds");
+        return IRS_ERR_UNSUPPORTED;
+    }
+    if (solver == 2 || (solver == 0 && one_box &&
+                        irs_ctrlbox_lds_bytes(model, T) <= (size_t)(160 * 1024 - 512))) {
+        rc = irs_ctrlbox_launch(model, a, du_lo != nullptr ? 1 : 0, st);
+        if (rc != IRS_OK) return rc;
+        IRS_CHECK_LAUNCH();
+        return IRS_OK;
+    }
     rc = IRS_ERR_UNSUPPORTED;
     IRS_DISPATCH_MODEL(model, {
         if constexpr (has_u_into_x<Model>::value) rc = launch_box<Model, true>(a, st);

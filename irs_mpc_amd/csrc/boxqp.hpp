@@ -1,0 +1,34 @@
+// Shared between the two bounded TV-LQR kernels (boxqp.hip: ADMM; ctrlbox.hip: active set).
+#pragma once
+#include <type_traits>
+
+#include "irs_common.hpp"
+
+struct BoxArgs {
+    ModelParams p;
+    const double *At, *Bt, *ct, *Q, *Qd, *R, *xd, *x0;
+    // bounds: row t at ptr + t * stride (stride 0 = one constant row); null = unbounded; +-inf ok
+    const double *xlo, *xhi;                 // on x_t, t = 0..T   (row 0 unused: x_0 is fixed)
+    const double *ulo, *uhi;                 // on u_t, t = 0..T-1
+    const double *dlo, *dhi;                 // DU only: on u_t - u_{t-1}
+    int sx, su, sd;
+    double *x_new, *u_new, *cost;            // cost may be null
+    int* info;                               // [0] Hessian not PD at t+1, [1] max ADMM iterations used,
+                                             // [2] number of tail problems that hit max_iter
+    double alpha, rho, relax, eps;
+    int T, max_iter;
+};
+
+// position-controlled models expose indices_u_into_x (quasistatic_dynamics.py:57-65)
+template <class M, class = void>
+struct has_u_into_x : std::false_type {};
+template <class M>
+struct has_u_into_x<M, std::void_t<decltype(M::u_into_x(0))>> : std::true_type {};
+
+
+// ctrlbox.hip: active-set solver for the quasistatic descent with ONE control box.
+// kind 0: bounds on u_t (a.ulo/a.uhi), kind 1: bounds on u_t - u_{t-1} (a.dlo/a.dhi); a bound pair
+// may be null (unbounded).  Returns IRS_ERR_UNSUPPORTED (message set) if the model is not position
+// controlled or the horizon does not fit LDS.
+int irs_ctrlbox_launch(int model, const BoxArgs& a, int kind, hipStream_t st);
+size_t irs_ctrlbox_lds_bytes(int model, int T);

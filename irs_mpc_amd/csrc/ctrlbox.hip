@@ -1,0 +1,577 @@
+// Quasistatic descent with ONE control box, solved exactly by an active-set method.
+//
+// IrsLqrQuasistatic.local_descent (irs_lqr/irs_lqr_quasistatic.py:286-345) re-solves, for every t,
+// the tail QP of solve_tvlqr (irs_lqr/tv_lqr.py:30-137, position-controlled branch: input cost on
+// du_t = u_t - u_{t-1}) and applies its first control to the true dynamics.  Every example of the
+// reference bounds EITHER u_t (u_bounds_abs: a trust region around the nominal actuated
+// positions) OR du_t (u_bounds_rel: a rate limit).  Writing the QP so that the bounded quantity is
+// the control of an LQR with state s = [x; w], w = u_{t-1},
+//     kind ABS: control u_t:         s+ = [[A,0],[0,0]] s + [B;I] u + [c;0],
+//               stage (x-xd)'Q(x-xd) + (u-w)'R(u-w) = (s-sd)'diag(Q,R)(s-sd) + u'Ru + 2 s'Nc u, Nc=[0;-R]
+//     kind REL: control v_t = du_t:  s+ = [[A,B],[0,I]] s + [B;I] v + [c;0],
+//               stage (x-xd)'Q(x-xd) + v'Rv
+// turns it into a control-box LQR: with the set of pinned control components fixed, the rest is an
+// equality-constrained LQR solved by ONE backward sweep (policy u = K s + k, cost-to-go (P,p)),
+// and that sweep does not depend on the start state.  So
+//   * the active set and the sweep are carried from tail to tail: an unchanged active set costs a
+//     forward vector sweep only, a changed one a PARTIAL backward sweep from the latest changed t;
+//   * phase 1 updates the set primal-dual style (pin every violated bound, release every
+//     wrong-signed multiplier at once: Hintermueller-Ito-Kunisch), which usually ends in a few
+//     iterations but may cycle; after kPdasIter iterations phase 2 continues with the classic
+//     primal active-set method (one constraint per iteration: blocking step or worst multiplier),
+//     which is finite and monotone for a strictly convex QP.
+// Restated in oracle/irs_oracle.py (quasistatic_ctrl_problem / ctrlbox_backward / ctrlbox_solve /
+// local_descent_quasistatic_as), checked there against the ADMM solution of the same QPs.
+//
+// One wave, f64, everything in (dynamic) LDS: a latency-bound chain like the Riccati pass.
+#include "boxqp.hpp"
+
+namespace {
+
+constexpr int kPdasIter = 10;
+constexpr int KIND_ABS = 0, KIND_REL = 1;
+
+__device__ __forceinline__ void wave_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v = fmax(v, __shfl_xor(v, s, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v = fmin(v, __shfl_xor(v, s, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v = max(v, __shfl_xor(v, s, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v = min(v, __shfl_xor(v, s, 64));
+    return v;
+}
+
+// LDS record of one time step (doubles).  Record T holds only P, p, s.
+template <int NR, int M>
+struct CbLayout {
+    static constexpr int NS = NR + M;
+    static constexpr int oP = 0, op = oP + NS * NS, oK = op + NS, ok = oK + M * NS, oH = ok + M,
+                         oG = oH + M * M, og = oG + M * NS, oA = og + M, oB = oA + NR * NR,
+                         oc = oB + NR * M, os = oc + NR, ou = os + NS, ous = ou + M, omu = ous + M,
+                         oact = omu + M, olo = oact + M, ohi = olo + M, S = ohi + M;
+    static constexpr int scratch = 2 * NS * NS + 3 * M * NS + 4 * NS + 3 * M * M + M * (NS + 1) +
+                                   2 * NR * NR + 64;
+    static __host__ __device__ size_t doubles(int T) { return (size_t)(T + 1) * S + scratch; }
+};
+
+template <class Model, int KIND>
+__global__ __launch_bounds__(64) void ctrlbox_descent_kernel(BoxArgs a) {
+    constexpr int NR = Model::NX, M = Model::NU, NS = NR + M;
+    constexpr double INF = __builtin_huge_val();
+    using L = CbLayout<NR, M>;
+    extern __shared__ double lds[];
+    const int T = a.T, lane = threadIdx.x;
+    double* F = lds;
+    double* PB = F + (size_t)(T + 1) * L::S;           // NS x M
+    double* Wm = PB + NS * M;                          // NS x NS
+    double* Pn = Wm + NS * NS;                         // NS x NS
+    double* Y = Pn + NS * NS;                          // M x NS
+    double* qv = Y + M * NS;                           // NS
+    double* hk = qv + NS;                              // M (padded NS)
+    double* Hm = hk + NS;                              // M x M
+    double* Hinv = Hm + M * M;                         // M x M
+    double* RHS = Hinv + M * M;                        // M x (NS+1)
+    double* Qsym = RHS + M * (NS + 1);                 // NR x NR
+    double* Qdsym = Qsym + NR * NR;                    // NR x NR
+    double* Rsym = Qdsym + NR * NR;                    // M x M
+    double* sstart = Rsym + M * M;                     // NS
+
+    auto rec_ = [&](int t) -> double* { return F + (size_t)t * L::S; };
+    // problem data of the LQR in s = [x; w]
+    auto A_ = [&](const double* rec, int i, int j) -> double {
+        if (i < NR) {
+            if (j < NR) return rec[L::oA + i * NR + j];
+            return KIND == KIND_REL ? rec[L::oB + i * M + (j - NR)] : 0.0;
+        }
+        return (KIND == KIND_REL && i == j) ? 1.0 : 0.0;
+    };
+    auto B_ = [&](const double* rec, int i, int j) -> double {
+        return i < NR ? rec[L::oB + i * M + j] : ((i - NR) == j ? 1.0 : 0.0);
+    };
+    auto Qs_ = [&](int i, int j) -> double {
+        if (i < NR && j < NR) return Qsym[i * NR + j];
+        if (KIND == KIND_ABS && i >= NR && j >= NR) return Rsym[(i - NR) * M + (j - NR)];
+        return 0.0;
+    };
+    auto Nc_ = [&](int i, int j) -> double {          // NS x M
+        return (KIND == KIND_ABS && i >= NR) ? -Rsym[(i - NR) * M + j] : 0.0;
+    };
+    auto sd_ = [&](int t, int i) -> double { return i < NR ? a.xd[(size_t)t * NR + i] : 0.0; };
+
+    // ---- setup ------------------------------------------------------------------------
+    for (int q = lane; q < NR * NR; q += 64) {
+        int i = q / NR, j = q % NR;
+        Qsym[q] = 0.5 * (a.Q[i * NR + j] + a.Q[j * NR + i]);
+        Qdsym[q] = 0.5 * (a.Qd[i * NR + j] + a.Qd[j * NR + i]);
+    }
+    for (int q = lane; q < M * M; q += 64) {
+        int i = q / M, j = q % M;
+        Rsym[q] = 0.5 * (a.R[i * M + j] + a.R[j * M + i]);
+    }
+    const double* blo = KIND == KIND_ABS ? a.ulo : a.dlo;
+    const double* bhi = KIND == KIND_ABS ? a.uhi : a.dhi;
+    const int bs = KIND == KIND_ABS ? a.su : a.sd;
+    for (int t = 0; t < T; ++t) {
+        double* rec = rec_(t);
+        for (int q = lane; q < NR * NR; q += 64) rec[L::oA + q] = a.At[(size_t)t * NR * NR + q];
+        for (int q = lane; q < NR * M; q += 64) rec[L::oB + q] = a.Bt[(size_t)t * NR * M + q];
+        if (lane < NR) rec[L::oc + lane] = a.ct[(size_t)t * NR + lane];
+        if (lane < M) {
+            rec[L::olo + lane] = blo ? blo[(size_t)t * bs + lane] : -INF;
+            rec[L::ohi + lane] = bhi ? bhi[(size_t)t * bs + lane] : INF;
+            rec[L::oact + lane] = 0.0;
+            rec[L::ou + lane] = 0.0;
+            rec[L::ous + lane] = 0.0;
+            rec[L::omu + lane] = 0.0;
+        }
+    }
+    wave_sync();
+    {   // terminal cost-to-go: P_T = Qsd, p_T = -Qsd sd_T  (Qsd = diag(Qd, 0))
+        double* rec = rec_(T);
+        for (int q = lane; q < NS * NS; q += 64) {
+            int i = q / NS, j = q % NS;
+            rec[L::oP + q] = (i < NR && j < NR) ? Qdsym[i * NR + j] : 0.0;
+        }
+        if (lane < NS) {
+            double s = 0.0;
+            if (lane < NR)
+                for (int j = 0; j < NR; ++j) s -= Qdsym[lane * NR + j] * a.xd[(size_t)T * NR + j];
+            rec[L::op + lane] = s;
+        }
+    }
+    wave_sync();
+
+    int bad = 0;
+    // ---- one backward step: policy (K,k) for the pinned set of step t, cost-to-go (P,p)_t ----
+    auto backward_step = [&](int t) {
+        double* rec = rec_(t);
+        const double* nxt = rec_(t + 1);
+        const double* P = nxt + L::oP;
+        const double* p = nxt + L::op;
+        // PB = P B_ ; qv = P c_ + p
+        for (int q = lane; q < NS * M; q += 64) {
+            int i = q / M, j = q % M;
+            double s = P[i * NS + NR + j];
+            for (int l = 0; l < NR; ++l) s += P[i * NS + l] * rec[L::oB + l * M + j];
+            PB[q] = s;
+        }
+        if (lane < NS) {
+            double s = p[lane];
+            for (int l = 0; l < NR; ++l) s += P[lane * NS + l] * rec[L::oc + l];
+            qv[lane] = s;
+        }
+        // W = P A_
+        for (int q = lane; q < NS * NS; q += 64) {
+            int i = q / NS, j = q % NS;
+            double s = 0.0;
+            for (int l = 0; l < NS; ++l) s += P[i * NS + l] * A_(rec, l, j);
+            Wm[q] = s;
+        }
+        wave_sync();
+        // H = Ru + B_'PB ; g = B_'qv ; G = PB'A_ + Nc'
+        for (int q = lane; q < M * M; q += 64) {
+            int i = q / M, j = q % M;
+            double s = Rsym[q] + PB[(NR + i) * M + j];
+            for (int l = 0; l < NR; ++l) s += rec[L::oB + l * M + i] * PB[l * M + j];
+            rec[L::oH + q] = s;
+        }
+        if (lane < M) {
+            double s = qv[NR + lane];
+            for (int l = 0; l < NR; ++l) s += rec[L::oB + l * M + lane] * qv[l];
+            rec[L::og + lane] = s;
+        }
+        for (int q = lane; q < M * NS; q += 64) {
+            int i = q / NS, j = q % NS;
+            double s = Nc_(j, i);
+            for (int l = 0; l < NS; ++l) s += PB[l * M + i] * A_(rec, l, j);
+            rec[L::oG + q] = s;
+        }
+        wave_sync();
+        // masked system: pinned rows/columns of H replaced by the identity
+        for (int q = lane; q < M * M; q += 64) {
+            int i = q / M, j = q % M;
+            const bool fi = rec[L::oact + i] == 0.0, fj = rec[L::oact + j] == 0.0;
+            Hm[q] = (fi && fj) ? rec[L::oH + q] : (i == j ? 1.0 : 0.0);
+        }
+        for (int q = lane; q < M * (NS + 1); q += 64) {
+            int i = q / (NS + 1), j = q % (NS + 1);
+            const double ai = rec[L::oact + i];
+            const double ubar = ai < 0.0 ? rec[L::olo + i] : rec[L::ohi + i];
+            double s;
+            if (ai == 0.0) {
+                if (j < NS) s = -rec[L::oG + i * NS + j];
+                else {
+                    s = -rec[L::og + i];
+                    for (int l = 0; l < M; ++l) {
+                        const double al = rec[L::oact + l];
+                        if (al != 0.0) s -= rec[L::oH + i * M + l] * (al < 0.0 ? rec[L::olo + l] : rec[L::ohi + l]);
+                    }
+                }
+            } else {
+                s = j < NS ? 0.0 : ubar;
+            }
+            RHS[q] = s;
+        }
+        wave_sync();
+        // Hm^-1 by LDL' in registers (every lane), lane j < M keeps column j
+        {
+            double Lm[M][M], Dg[M], Dinv[M];
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                double dj = Hm[j * M + j];
+#pragma unroll
+                for (int l = 0; l < j; ++l) dj -= Lm[j][l] * Lm[j][l] * Dg[l];
+                if (!(dj > 0.0) && bad == 0) bad = t + 1;
+                Dg[j] = dj;
+                Dinv[j] = 1.0 / dj;
+#pragma unroll
+                for (int i = j + 1; i < M; ++i) {
+                    double s = Hm[i * M + j];
+#pragma unroll
+                    for (int l = 0; l < j; ++l) s -= Lm[i][l] * Lm[j][l] * Dg[l];
+                    Lm[i][j] = s * Dinv[j];
+                }
+            }
+            if (lane < M) {
+                double y[M];
+#pragma unroll
+                for (int i = 0; i < M; ++i) {
+                    double s = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int l = 0; l < i; ++l) s -= Lm[i][l] * y[l];
+                    y[i] = s;
+                }
+#pragma unroll
+                for (int i = M - 1; i >= 0; --i) {
+                    double s = y[i] * Dinv[i];
+#pragma unroll
+                    for (int l = i + 1; l < M; ++l) s -= Lm[l][i] * y[l];
+                    y[i] = s;
+                }
+#pragma unroll
+                for (int i = 0; i < M; ++i) Hinv[i * M + lane] = y[i];
+            }
+        }
+        wave_sync();
+        // [K | k] = Hm^-1 RHS
+        for (int q = lane; q < M * (NS + 1); q += 64) {
+            int i = q / (NS + 1), j = q % (NS + 1);
+            double s = 0.0;
+            for (int l = 0; l < M; ++l) s += Hinv[i * M + l] * RHS[l * (NS + 1) + j];
+            if (j < NS) rec[L::oK + i * NS + j] = s;
+            else rec[L::ok + i] = s;
+        }
+        wave_sync();
+        // Y = H K + G ; hk = H k + g
+        for (int q = lane; q < M * NS; q += 64) {
+            int i = q / NS, j = q % NS;
+            double s = rec[L::oG + q];
+            for (int l = 0; l < M; ++l) s += rec[L::oH + i * M + l] * rec[L::oK + l * NS + j];
+            Y[q] = s;
+        }
+        if (lane < M) {
+            double s = rec[L::og + lane];
+            for (int l = 0; l < M; ++l) s += rec[L::oH + lane * M + l] * rec[L::ok + l];
+            hk[lane] = s;
+        }
+        wave_sync();
+        // P_t = sym(Qs + A_'W + K'Y + G'K) ; p_t = -Qs sd_t + A_'qv + K'hk + G'k
+        for (int q = lane; q < NS * NS; q += 64) {
+            int i = q / NS, j = q % NS;
+            double s = 0.0, s2 = 0.0;
+            for (int l = 0; l < NS; ++l) {
+                s += A_(rec, l, i) * Wm[l * NS + j];
+                s2 += A_(rec, l, j) * Wm[l * NS + i];
+            }
+            for (int l = 0; l < M; ++l) {
+                s += rec[L::oK + l * NS + i] * Y[l * NS + j] + rec[L::oG + l * NS + i] * rec[L::oK + l * NS + j];
+                s2 += rec[L::oK + l * NS + j] * Y[l * NS + i] + rec[L::oG + l * NS + j] * rec[L::oK + l * NS + i];
+            }
+            Pn[q] = Qs_(i, j) + 0.5 * (s + s2);
+        }
+        if (lane < NS) {
+            double s = 0.0;
+            for (int j = 0; j < NS; ++j) s -= Qs_(lane, j) * sd_(t, j);
+            for (int l = 0; l < NS; ++l) s += A_(rec, l, lane) * qv[l];
+            for (int l = 0; l < M; ++l) s += rec[L::oK + l * NS + lane] * hk[l] + rec[L::oG + l * NS + lane] * rec[L::ok + l];
+            rec[L::op + lane] = s;
+        }
+        wave_sync();
+        for (int q = lane; q < NS * NS; q += 64) rec[L::oP + q] = Pn[q];
+        wave_sync();
+    };
+
+    // ---- policy rollout on the linear model from sstart: controls -> record offset `dst`, mu ----
+    auto policy_rollout = [&](int t0, int dst) {
+        if (lane < NS) rec_(t0)[L::os + lane] = sstart[lane];
+        wave_sync();
+        for (int t = t0; t < T; ++t) {
+            double* rec = rec_(t);
+            if (lane < M) {
+                double s = rec[L::ok + lane];
+                for (int l = 0; l < NS; ++l) s += rec[L::oK + lane * NS + l] * rec[L::os + l];
+                rec[dst + lane] = s;
+            }
+            wave_sync();
+            if (lane < M) {
+                double s = rec[L::og + lane];
+                for (int l = 0; l < M; ++l) s += rec[L::oH + lane * M + l] * rec[dst + l];
+                for (int l = 0; l < NS; ++l) s += rec[L::oG + lane * NS + l] * rec[L::os + l];
+                rec[L::omu + lane] = s;
+            } else if (lane < M + NS) {
+                const int i = lane - M;
+                double s = i < NR ? rec[L::oc + i] : 0.0;
+                for (int l = 0; l < NS; ++l) s += A_(rec, i, l) * rec[L::os + l];
+                for (int j = 0; j < M; ++j) s += B_(rec, i, j) * rec[dst + j];
+                rec_(t + 1)[L::os + i] = s;
+            }
+            wave_sync();
+        }
+    };
+
+    // ---- MPC loop --------------------------------------------------------------------
+    double xr[NR], ur[M], xn[NR], up[M];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) xr[i] = a.x0[i];
+#pragma unroll
+    for (int j = 0; j < M; ++j) up[j] = 0.0;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) a.x_new[i] = xr[i];
+    }
+    auto quad = [&](const double* Wq, const double* e, int Kd) -> double {
+        double s = 0.0;
+        for (int i = 0; i < Kd; ++i)
+            for (int j = 0; j < Kd; ++j) s += e[i] * Wq[i * Kd + j] * e[j];
+        return s;
+    };
+    double cost = 0.0;
+    int it_max = 0, n_fail = 0;
+    const double tol = a.eps;
+    bool full = true;                                  // no valid backward sweep yet
+
+    for (int tau = 0; tau < T; ++tau) {
+        // start state [x; x[idx]]: each tail's first du is measured from the realised actuated
+        // position (tv_lqr.py:99-100 at the tail's local t = 0)
+        double ub[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            double v = xr[0];
+#pragma unroll
+            for (int i = 1; i < NR; ++i) v = (i == Model::u_into_x(j)) ? xr[i] : v;
+            ub[j] = v;
+        }
+        if (lane < NS) {
+            double v = xr[0];
+#pragma unroll
+            for (int i = 1; i < NR; ++i) v = (i == lane) ? xr[i] : v;
+#pragma unroll
+            for (int j = 0; j < M; ++j) v = (NR + j == lane) ? ub[j] : v;
+            sstart[lane] = v;
+        }
+        wave_sync();
+        const int t0 = tau;
+        int t_dirty = full ? T - 1 : t0 - 1;           // the sweep of the previous tail covers t >= tau
+        int iters = 0;
+        bool conv = false;
+        // ---- phase 1: primal-dual active set
+        for (int it = 0; it < kPdasIter && !conv; ++it) {
+            ++iters;
+            for (int t = t_dirty; t >= t0; --t) backward_step(t);
+            policy_rollout(t0, L::ou);
+            int chg = -1;
+            for (int q = t0 * M + lane; q < T * M; q += 64) {
+                const int t = q / M, j = q % M;
+                double* rec = rec_(t);
+                const double ac = rec[L::oact + j], u = rec[L::ou + j], mu = rec[L::omu + j];
+                double nw = ac;
+                if (ac == 0.0) {
+                    if (u < rec[L::olo + j] - tol) nw = -1.0;
+                    else if (u > rec[L::ohi + j] + tol) nw = 1.0;
+                } else if (ac < 0.0) {
+                    if (mu < -tol) nw = 0.0;
+                } else {
+                    if (mu > tol) nw = 0.0;
+                }
+                if (nw != ac) { rec[L::oact + j] = nw; chg = max(chg, t); }
+            }
+            chg = wave_max_i(chg);
+            wave_sync();
+            if (chg < 0) conv = true;
+            else t_dirty = chg;
+        }
+        // ---- phase 2: primal active set from the clipped iterate
+        if (!conv) {
+            int chg = -1;
+            for (int q = t0 * M + lane; q < T * M; q += 64) {
+                const int t = q / M, j = q % M;
+                double* rec = rec_(t);
+                const double lo = rec[L::olo + j], hi = rec[L::ohi + j];
+                const double u = fmin(fmax(rec[L::ou + j], lo), hi);
+                rec[L::ou + j] = u;
+                const double nw = u <= lo ? -1.0 : (u >= hi ? 1.0 : 0.0);
+                if (nw != rec[L::oact + j]) { rec[L::oact + j] = nw; chg = max(chg, t); }
+            }
+            chg = wave_max_i(chg);
+            wave_sync();
+            t_dirty = max(t_dirty, chg);
+            for (int it2 = 0; it2 < a.max_iter && !conv; ++it2) {
+                ++iters;
+                for (int t = t_dirty; t >= t0; --t) backward_step(t);
+                t_dirty = t0 - 1;
+                policy_rollout(t0, L::ous);
+                // largest feasible step along d = us - u over the free components
+                double best = INF;
+                int bq = 0x7fffffff;
+                for (int q = t0 * M + lane; q < T * M; q += 64) {
+                    const int t = q / M, j = q % M;
+                    const double* rec = rec_(t);
+                    if (rec[L::oact + j] == 0.0) {
+                        const double u = rec[L::ou + j], d = rec[L::ous + j] - u;
+                        double room = INF;
+                        if (d > 0.0) room = (rec[L::ohi + j] - u) / d;
+                        else if (d < 0.0) room = (rec[L::olo + j] - u) / d;
+                        if (room < best) { best = room; bq = q; }
+                    }
+                }
+                const double alpha = wave_min(best);
+                if (alpha < 1.0) {
+                    const int qb = wave_min_i(best == alpha ? bq : 0x7fffffff);
+                    for (int q = t0 * M + lane; q < T * M; q += 64) {
+                        const int t = q / M, j = q % M;
+                        double* rec = rec_(t);
+                        const double u = rec[L::ou + j], d = rec[L::ous + j] - u;
+                        if (q == qb) {
+                            rec[L::oact + j] = d > 0.0 ? 1.0 : -1.0;
+                            rec[L::ou + j] = d > 0.0 ? rec[L::ohi + j] : rec[L::olo + j];
+                        } else {
+                            rec[L::ou + j] = u + alpha * d;
+                        }
+                    }
+                    wave_sync();
+                    t_dirty = qb / M;
+                    continue;
+                }
+                // full step: u = us; optimal if every pinned multiplier has the right sign
+                double worst = 0.0;
+                int wq = 0x7fffffff;
+                for (int q = t0 * M + lane; q < T * M; q += 64) {
+                    const int t = q / M, j = q % M;
+                    double* rec = rec_(t);
+                    rec[L::ou + j] = rec[L::ous + j];
+                    const double ac = rec[L::oact + j], mu = rec[L::omu + j];
+                    const double viol = ac < 0.0 ? -mu : (ac > 0.0 ? mu : 0.0);
+                    if (viol > worst) { worst = viol; wq = q; }
+                }
+                const double wmax = wave_max(worst);
+                if (wmax <= tol) {
+                    wave_sync();
+                    conv = true;
+                } else {
+                    const int qw = wave_min_i(worst == wmax ? wq : 0x7fffffff);
+                    if (lane == 0) rec_(qw / M)[L::oact + qw % M] = 0.0;
+                    wave_sync();
+                    t_dirty = qw / M;
+                }
+            }
+        }
+        it_max = max(it_max, iters);
+        n_fail += conv ? 0 : 1;
+        full = !conv;
+        // first control of the tail solution (clipped), true dynamics step
+        {
+            const double* rec = rec_(tau);
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                const double v = fmin(fmax(rec[L::ou + j], rec[L::olo + j]), rec[L::ohi + j]);
+                ur[j] = KIND == KIND_ABS ? v : ub[j] + v;
+            }
+        }
+        {   // IrsLqrQuasistatic.eval_cost (irs_lqr_quasistatic.py:153-194)
+            double e[NR], dv[M];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) e[i] = xr[i] - a.xd[(size_t)tau * NR + i];
+#pragma unroll
+            for (int j = 0; j < M; ++j) dv[j] = ur[j] - (tau == 0 ? ub[j] : up[j]);
+            cost += quad(Qsym, e, NR) + quad(Rsym, dv, M);
+        }
+        Model::template step<double>(a.p, xr, ur, xn);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) xr[i] = xn[i];
+#pragma unroll
+        for (int j = 0; j < M; ++j) up[j] = ur[j];
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < M; ++j) a.u_new[(size_t)tau * M + j] = ur[j];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) a.x_new[(size_t)(tau + 1) * NR + i] = xr[i];
+        }
+        wave_sync();
+    }
+    {
+        double e[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) e[i] = xr[i] - a.xd[(size_t)T * NR + i];
+        cost += quad(Qdsym, e, NR);
+    }
+    if (lane == 0) {
+        a.info[0] = bad; a.info[1] = it_max; a.info[2] = n_fail;
+        if (a.cost) a.cost[0] = cost;
+    }
+}
+
+template <class Model, int KIND>
+int launch_ctrlbox(const BoxArgs& a, hipStream_t st) {
+    const size_t bytes = CbLayout<Model::NX, Model::NU>::doubles(a.T) * sizeof(double);
+    if (bytes > 160 * 1024 - 512) {
+        irs_set_error("irs_quasistatic_box_descent: horizon T=%d needs %zu bytes of LDS (max ~160 KB)", a.T, bytes);
+        return IRS_ERR_UNSUPPORTED;
+    }
+    auto kern = ctrlbox_descent_kernel<Model, KIND>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        irs_set_error("irs_quasistatic_box_descent: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return IRS_ERR_HIP;
+    }
+    hipLaunchKernelGGL(kern, dim3(1), dim3(64), bytes, st, a);
+    return IRS_OK;
+}
+
+}  // namespace
+
+int irs_ctrlbox_launch(int model, const BoxArgs& a, int kind, hipStream_t st) {
+    int rc = IRS_ERR_UNSUPPORTED;
+    IRS_DISPATCH_MODEL(model, {
+        if constexpr (has_u_into_x<Model>::value) {
+            rc = kind == KIND_ABS ? launch_ctrlbox<Model, KIND_ABS>(a, st) : launch_ctrlbox<Model, KIND_REL>(a, st);
+        } else {
+            irs_set_error("irs_quasistatic_box_descent: model %d is not position controlled", model);
+        }
+    });
+    return rc;
+}
+
+size_t irs_ctrlbox_lds_bytes(int model, int T) {
+    size_t r = 0;
+    IRS_DISPATCH_MODEL(model, {
+        if constexpr (has_u_into_x<Model>::value) r = CbLayout<Model::NX, Model::NU>::doubles(T) * sizeof(double);
+    });
+    return r;
+}

@@ -33,7 +33,7 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kWaves = kBlock / 64;
+
 constexpr int kCounterBytes = 4096;   // head of the workspace: arrival counters
 
 template <class Model, int MODE>

@@ -176,15 +176,17 @@ class DeviceModel:
               "irs_tvlqr_box_descent")
         return o
 
-    def quasistatic_descent_supported(self, T):
-        return 0 < self.lib.irs_quasistatic_box_lds_bytes(self.model_id, int(T)) <= self.BOX_LDS_LIMIT
+    SOLVER_AUTO, SOLVER_ADMM, SOLVER_ACTIVE_SET = 0, 1, 2
+
+    def quasistatic_descent_supported(self, T, solver=1):
+        return 0 < self.lib.irs_quasistatic_box_lds_bytes(self.model_id, int(T), int(solver)) <= self.BOX_LDS_LIMIT
 
     def quasistatic_box_descent(self, At, Bt, ct, Q, Qd, R, xd_trj, x0, x_lo=None, x_hi=None, u_lo=None,
-                                u_hi=None, du_lo=None, du_hi=None, rho=10.0, relax=1.6, max_iter=5000,
-                                eps=1e-8, out=None):
+                                u_hi=None, du_lo=None, du_hi=None, solver=0, rho=10.0, relax=1.6,
+                                max_iter=5000, eps=1e-8, out=None):
         """IrsLqrQuasistatic.local_descent after get_TV_matrices (irs_lqr_quasistatic.py:286-345) +
-        eval_cost.  Bounds are absolute per-time rows ((T+1,n) / (T,m)) or None.
-        Returns dict(x_new, u_new, cost, info[3])."""
+        eval_cost.  Bounds are absolute per-time rows ((T+1,n) / (T,m)) or None.  solver: 0 auto,
+        1 ADMM, 2 active set (one control box, no x bounds).  Returns dict(x_new, u_new, cost, info[3])."""
         T = At.shape[0]
         dev = At.device
         o = out
@@ -199,8 +201,8 @@ class DeviceModel:
         check(self.lib.irs_quasistatic_box_descent(
             self.model_id, self._p, self._np, T, _ptr(At, F64), _ptr(Bt, F64), _ptr(ct, F64), _ptr(Q, F64),
             _ptr(Qd, F64), _ptr(R, F64), _ptr(xd_trj, F64), _ptr(x0, F64), _ptr(x_lo, F64), _ptr(x_hi, F64),
-            _ptr(u_lo, F64), _ptr(u_hi, F64), _ptr(du_lo, F64), _ptr(du_hi, F64), float(rho), float(relax),
-            int(max_iter), float(eps), _ptr(o["x_new"], F64), _ptr(o["u_new"], F64), _ptr(o["cost"], F64),
+            _ptr(u_lo, F64), _ptr(u_hi, F64), _ptr(du_lo, F64), _ptr(du_hi, F64), int(solver), float(rho),
+            float(relax), int(max_iter), float(eps), _ptr(o["x_new"], F64), _ptr(o["u_new"], F64), _ptr(o["cost"], F64),
             o["info"].data_ptr(), _stream()), "irs_quasistatic_box_descent")
         return o
 

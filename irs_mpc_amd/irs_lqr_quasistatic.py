@@ -70,9 +70,10 @@ class IrsLqrQuasistaticParameters:
 
         # ---- extensions (absent in the reference) ----
         self.device_rng_seed = None     # int: draw the perturbations on the device
-        self.qp_rho = 10.0              # ADMM penalty / iteration limit / tolerance of the bounded QPs
-        self.qp_max_iter = 5000
-        self.qp_eps = 1e-8
+        self.qp_solver = 0              # 0 auto, 1 ADMM, 2 active set (include/irs_hip.h)
+        self.qp_rho = 100.0             # ADMM penalty / iteration limit / tolerance of the bounded QPs
+        self.qp_max_iter = 20000
+        self.qp_eps = 1e-9
 
 
 class IrsLqrQuasistatic:
@@ -116,7 +117,11 @@ class IrsLqrQuasistatic:
 
         # device-resident problem data (f64)
         self._dm = q_dynamics.dm()
-        if not self._dm.quasistatic_descent_supported(self.T):
+        one_box = self.x_bounds_abs is None and (self.u_bounds_abs is None or self.u_bounds_rel is None)
+        self._solver = int(getattr(params, "qp_solver", 0))
+        if self._solver == 0:
+            self._solver = 2 if one_box and self._dm.quasistatic_descent_supported(self.T, 2) else 1
+        if not self._dm.quasistatic_descent_supported(self.T, self._solver):
             raise NotImplementedError("horizon T=%d does not fit the LDS-resident QP factorisation" % self.T)
         self._Q, self._Qd, self._R = (dev.to_dev(np.asarray(a, float)) for a in (self.Q, self.Qd, self.R))
         self._x0 = dev.to_dev(np.asarray(self.x0, float))
@@ -268,9 +273,9 @@ class IrsLqrQuasistatic:
         p = self.params
         o = self._dm.quasistatic_box_descent(At, Bt, ct, self._Q, self._Qd, self._R, self._xd,
                                              x_trj[0].contiguous(), *self._bounds_dev(x_trj),
-                                             rho=getattr(p, "qp_rho", 10.0),
-                                             max_iter=getattr(p, "qp_max_iter", 5000),
-                                             eps=getattr(p, "qp_eps", 1e-8))
+                                             solver=self._solver, rho=getattr(p, "qp_rho", 100.0),
+                                             max_iter=getattr(p, "qp_max_iter", 20000),
+                                             eps=getattr(p, "qp_eps", 1e-9))
         self._last = dict(At=At, Bt=Bt, ct=ct, info=o["info"])
         return o["x_new"], o["u_new"], o["cost"]
 

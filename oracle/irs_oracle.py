@@ -995,3 +995,181 @@ def local_descent_quasistatic(system, At, Bt, ct, Q, Qd, R, x0, xd_trj, x_lo, x_
         u_new[t] = np.clip(z_t[n:] + v, u_lo[t], u_hi[t])
         x_new[t + 1] = system.dynamics(x_new[t], u_new[t])
     return x_new, u_new, iters
+
+
+# --------------------------------------------------------------------------
+# Control-box LQR by a primal-dual active-set method (the fast path of the device's quasistatic
+# descent when only ONE of u_bounds_abs / u_bounds_rel is given -- all the reference's examples)
+# --------------------------------------------------------------------------
+def quasistatic_ctrl_problem(At, Bt, ct, Q, Qd, R, xd_trj, kind):
+    """The QP of tv_lqr.py:69-137 (position-controlled branch) written so that the BOUNDED
+    quantity is the control of an LQR with state s = [x; u_prev]:
+      kind "rel": control v_t = u_t - u_{t-1};  s+ = [[A,B],[0,I]] s + [B;I] v + [c;0];
+                  stage cost (x-xd)'Q(x-xd) + v'Rv
+      kind "abs": control u_t;                  s+ = [[A,0],[0,0]] s + [B;I] u + [c;0];
+                  stage cost (x-xd)'Q(x-xd) + (u-w)'R(u-w)  =  (s-sd)'diag(Q,R)(s-sd) + u'Ru + 2 s'Nc u,
+                  Nc = [0; -R]
+    Returns dict(A,B,c (T,..), Qs, Qsd, Nc, Ru, sd (T+1, n+m))."""
+    T, n, m = Bt.shape
+    Ns = n + m
+    A, B, c = np.zeros((T, Ns, Ns)), np.zeros((T, Ns, m)), np.zeros((T, Ns))
+    A[:, :n, :n] = At
+    B[:, :n], B[:, n:] = Bt, np.eye(m)
+    c[:, :n] = ct
+    Qs, Qsd, Nc = np.zeros((Ns, Ns)), np.zeros((Ns, Ns)), np.zeros((Ns, m))
+    Qs[:n, :n], Qsd[:n, :n] = Q, Qd
+    if kind == "rel":
+        A[:, :n, n:] = Bt
+        A[:, n:, n:] = np.eye(m)
+    elif kind == "abs":
+        Qs[n:, n:] = R
+        Nc[n:] = -R
+    else:
+        raise ValueError(kind)
+    sd = np.hstack([xd_trj, np.zeros((T + 1, m))])
+    return dict(A=A, B=B, c=c, Qs=Qs, Qsd=Qsd, Nc=Nc, Ru=0.5 * (R + R.T), sd=sd, n=n, m=m, kind=kind)
+
+
+def ctrlbox_backward(prob, act, lo, hi, t_hi, t_lo, W):
+    """Policy evaluation/improvement sweep t = t_hi .. t_lo (inclusive, descending) for the
+    active sets act (T,m) in {-1: at lo, 0: free, +1: at hi}: free components are minimised, pinned
+    ones are constants.  W caches per-time (P, p, K, k, H, G, g); row t_hi+1 of P,p must be valid.
+    V_t(s) = s'P s + 2 p's + const."""
+    A, B, c, Qs, Nc, Ru, sd = (prob[k] for k in ("A", "B", "c", "Qs", "Nc", "Ru", "sd"))
+    m = prob["m"]
+    for t in range(t_hi, t_lo - 1, -1):
+        P, p = W["P"][t + 1], W["p"][t + 1]
+        PB = P @ B[t]
+        H = Ru + B[t].T @ PB
+        G = PB.T @ A[t] + Nc.T
+        q = P @ c[t] + p
+        g = B[t].T @ q
+        free = act[t] == 0
+        ubar = np.where(act[t] < 0, lo[t], hi[t])
+        K, k = np.zeros((m, A.shape[1])), np.where(free, 0.0, ubar)
+        if free.any():
+            Hff = H[np.ix_(free, free)]
+            rhs_k = g[free] + H[np.ix_(free, ~free)] @ ubar[~free]
+            K[free] = -np.linalg.solve(Hff, G[free])
+            k[free] = -np.linalg.solve(Hff, rhs_k)
+        Pn = Qs + A[t].T @ P @ A[t] + K.T @ H @ K + K.T @ G + G.T @ K
+        W["P"][t] = 0.5 * (Pn + Pn.T)
+        W["p"][t] = -Qs @ sd[t] + A[t].T @ q + K.T @ (H @ k + g) + G.T @ k
+        W["K"][t], W["k"][t], W["H"][t], W["G"][t], W["g"][t] = K, k, H, G, g
+
+
+def ctrlbox_solve(prob, s_start, t0, lo, hi, u, act, W, valid_from, pdas_iter=10, max_iter=2000, tol=1e-10):
+    """Active-set solve of the tail t0..T-1 from s_start.  `act` (T,m) in {-1 at lo, 0 free, +1 at hi}
+    is the warm start (updated in place), W the backward-pass cache valid for t >= valid_from
+    (T = nothing valid), `u` (T,m) receives the solution.
+      phase 1: primal-dual active-set iterations (Hintermueller-Ito-Kunisch): all violated bounds
+               are pinned and all wrong-signed multipliers released at once; converges in a handful
+               of iterations when it converges, but may cycle;
+      phase 2 (after pdas_iter iterations): classic primal active-set from the clipped iterate --
+               one constraint added (blocking step) or dropped (worst multiplier) per iteration;
+               finite and monotone for a strictly convex QP.
+    Every iteration is a partial backward sweep (from the latest changed time step) plus vector
+    sweeps.  Returns s, u, mu (half-gradient wrt u), (pdas iterations, primal iterations, backward
+    time steps swept), valid_from."""
+    T, m = prob["B"].shape[0], prob["m"]
+    A, B, c = prob["A"], prob["B"], prob["c"]
+    s = np.zeros((T + 1, A.shape[1]))
+    mu = np.zeros((T, m))
+    swept = 0
+
+    def backward(t_hi):
+        nonlocal swept
+        if t_hi >= t0:
+            ctrlbox_backward(prob, act, lo, hi, t_hi, t0, W)
+            swept += t_hi - t0 + 1
+
+    def policy_rollout(us):
+        s[t0] = s_start
+        for t in range(t0, T):
+            us[t] = W["K"][t] @ s[t] + W["k"][t]
+            mu[t] = W["H"][t] @ us[t] + W["G"][t] @ s[t] + W["g"][t]
+            s[t + 1] = A[t] @ s[t] + B[t] @ us[t] + c[t]
+
+    t_dirty = T - 1 if valid_from >= T else (valid_from - 1 if valid_from > t0 else t0 - 1)
+    # ---- phase 1: primal-dual active set
+    for it in range(1, pdas_iter + 1):
+        backward(t_dirty)
+        policy_rollout(u)
+        a, uu, mm = act[t0:], u[t0:], mu[t0:]
+        new = a.copy()
+        new[(a == 0) & (uu < lo[t0:] - tol)] = -1
+        new[(a == 0) & (uu > hi[t0:] + tol)] = 1
+        new[(a < 0) & (mm < -tol)] = 0
+        new[(a > 0) & (mm > tol)] = 0
+        changed = np.nonzero((new != a).any(axis=1))[0]
+        if changed.size == 0:
+            return s, u, mu, (it, 0, swept), t0
+        act[t0:] = new
+        t_dirty = t0 + int(changed.max())
+    # ---- phase 2: primal active set from the clipped iterate
+    u[t0:] = np.clip(u[t0:], lo[t0:], hi[t0:])
+    new = np.where(u[t0:] <= lo[t0:], -1, np.where(u[t0:] >= hi[t0:], 1, 0))
+    changed = np.nonzero((new != act[t0:]).any(axis=1))[0]
+    act[t0:] = new
+    t_dirty = max(t_dirty, t0 + int(changed.max())) if changed.size else t_dirty
+    us = np.zeros_like(u)
+    for it2 in range(1, max_iter + 1):
+        backward(t_dirty)
+        t_dirty = t0 - 1
+        policy_rollout(us)
+        d = us[t0:] - u[t0:]
+        free = act[t0:] == 0
+        # largest feasible step along d
+        with np.errstate(divide="ignore", invalid="ignore"):
+            room = np.where(d > 0, (hi[t0:] - u[t0:]) / d, np.where(d < 0, (lo[t0:] - u[t0:]) / d, np.inf))
+        room = np.where(free, room, np.inf)
+        alpha = min(1.0, room.min())
+        if alpha < 1.0:
+            r, j = np.unravel_index(np.argmin(room), room.shape)
+            u[t0:] += alpha * d
+            act[t0 + r, j] = 1 if d[r, j] > 0 else -1
+            u[t0 + r, j] = hi[t0 + r, j] if d[r, j] > 0 else lo[t0 + r, j]
+            t_dirty = t0 + r
+            continue
+        u[t0:] = us[t0:]
+        viol = np.where(act[t0:] < 0, -mu[t0:], np.where(act[t0:] > 0, mu[t0:], 0.0))   # > 0 = wrong sign
+        if viol.max() <= tol:
+            return s, u, mu, (pdas_iter, it2, swept), t0
+        r, j = np.unravel_index(np.argmax(viol), viol.shape)
+        act[t0 + r, j] = 0
+        t_dirty = t0 + r
+    return s, u, mu, (pdas_iter, -max_iter, swept), t0
+
+
+def ctrlbox_workspace(prob):
+    T, Ns, m = prob["B"].shape[0], prob["A"].shape[1], prob["m"]
+    W = dict(P=np.zeros((T + 1, Ns, Ns)), p=np.zeros((T + 1, Ns)), K=np.zeros((T, m, Ns)), k=np.zeros((T, m)),
+             H=np.zeros((T, m, m)), G=np.zeros((T, m, Ns)), g=np.zeros((T, m)))
+    W["P"][T] = prob["Qsd"]
+    W["p"][T] = -prob["Qsd"] @ prob["sd"][T]
+    return W
+
+
+def local_descent_quasistatic_as(system, At, Bt, ct, Q, Qd, R, x0, xd_trj, lo, hi, kind, pdas_iter=10,
+                                 max_iter=2000, tol=1e-10):
+    """irs_lqr_quasistatic.py:326-345 with ONE control box (kind "abs": lo,hi (T,m) absolute rows
+    on u_t; kind "rel": rows on u_t - u_{t-1}): T tail QPs solved EXACTLY by the active-set method,
+    the active set and the backward pass carried from tail to tail."""
+    T, n, m = Bt.shape
+    idx = system.indices_u_into_x
+    prob = quasistatic_ctrl_problem(At, Bt, ct, Q, Qd, R, xd_trj, kind)
+    W = ctrlbox_workspace(prob)
+    act = np.zeros((T, m), dtype=int)
+    x_new, u_new = np.zeros((T + 1, n)), np.zeros((T, m))
+    x_new[0] = x0
+    stats, valid_from = [], T
+    u = np.zeros((T, m))
+    for t in range(T):
+        s_t = np.concatenate([x_new[t], x_new[t][idx]])
+        s, u, mu, st, valid_from = ctrlbox_solve(prob, s_t, t, lo, hi, u, act, W, valid_from, pdas_iter,
+                                                 max_iter, tol)
+        stats.append(st)
+        ctl = np.clip(u[t], lo[t], hi[t])
+        u_new[t] = ctl if kind == "abs" else s_t[n:] + ctl
+        x_new[t + 1] = system.dynamics(x_new[t], u_new[t])
+    return x_new, u_new, stats

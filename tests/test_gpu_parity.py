@@ -813,9 +813,22 @@ def test_quasistatic_box_descent_vs_oracle(amd, bounds):
     dm = sys_d.dm()
     rows_d = [dev.to_dev(r) if np.isfinite(r).any() else None for r in rows]
     o = dm.quasistatic_box_descent(*[dev.to_dev(a) for a in (At, Bt, ct, Q, Qd, R, xd, x0)], *rows_d,
-                                   rho=100.0, relax=1.6, max_iter=40000, eps=1e-10)
+                                   solver=1, rho=100.0, relax=1.6, max_iter=40000, eps=1e-10)
     info = o["info"].cpu().numpy()
     assert info[0] == 0 and info[2] == 0, info
+    if bounds in ("abs", "rel"):
+        # the exact active-set solver on the same QPs: device == its oracle twin == the ADMM answer
+        o2 = dm.quasistatic_box_descent(*[dev.to_dev(a) for a in (At, Bt, ct, Q, Qd, R, xd, x0)], *rows_d,
+                                        solver=2, max_iter=2000, eps=1e-10)
+        i2 = o2["info"].cpu().numpy()
+        assert i2[0] == 0 and i2[2] == 0, i2
+        lo, hi = (rows[2], rows[3]) if bounds == "abs" else (rows[4], rows[5])
+        xa, ua, _ = orc.local_descent_quasistatic_as(sys_o, At, Bt, ct, Q, Qd, R, x0, xd, lo, hi, bounds)
+        np.testing.assert_allclose(o2["u_new"].cpu().numpy(), ua, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(o2["x_new"].cpu().numpy(), xa, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(ua, uo, rtol=0, atol=2e-7)
+        np.testing.assert_allclose(float(o2["cost"].item()), orc.eval_cost_quasistatic(xa, ua, xd, Q, Qd, R, idx),
+                                   rtol=1e-10)
     np.testing.assert_allclose(o["u_new"].cpu().numpy(), uo, rtol=0, atol=2e-7)
     np.testing.assert_allclose(o["x_new"].cpu().numpy(), xo, rtol=0, atol=2e-7)
     np.testing.assert_allclose(float(o["cost"].item()), orc.eval_cost_quasistatic(xo, uo, xd, Q, Qd, R, idx),
@@ -869,3 +882,41 @@ def test_irs_lqr_quasistatic_host_twin(amd):
     sol.iterate(3)
     assert len(sol.cost_all_list) == 5 and sol.cost_best < c0
     assert sol.x_trj_best.shape == (T + 1, 7) and sol.current_iter == 4
+
+
+@pytest.mark.parametrize("kind", ["abs", "rel", "none"])
+def test_quasistatic_active_set_full_horizon(amd, kind):
+    """BASELINE's planar_hand horizon (T=50): the active-set descent == its oracle twin; the "rel"
+    case needs the primal safeguard on some tails (the primal-dual iteration cycles there)."""
+    from irs_mpc_amd import device as dev
+    T = 50
+    sys_d, sys_o, x0, u_trj, x_trj, _, (At, Bt, ct), (Q, Qd, R, xd) = _hand_problem(amd, T, 200, 33)
+    idx = sys_o.indices_u_into_x
+    ub = np.array([-np.ones(4) * 0.05, np.ones(4) * 0.05]) if kind == "abs" else None
+    rb = np.array([-np.ones(4) * 0.03, np.ones(4) * 0.03]) if kind == "rel" else None
+    rows = orc.quasistatic_bounds(x_trj, idx, None, ub, rb)
+    lo, hi = (rows[4], rows[5]) if kind == "rel" else (rows[2], rows[3])
+    xa, ua, stats = orc.local_descent_quasistatic_as(sys_o, At, Bt, ct, Q, Qd, R, x0, xd, lo, hi,
+                                                     "rel" if kind == "rel" else "abs")
+    assert all(st[1] >= 0 for st in stats)
+    dm = sys_d.dm()
+    assert dm.quasistatic_descent_supported(T, 2)
+    rows_d = [dev.to_dev(r) if np.isfinite(r).any() else None for r in rows]
+    o = dm.quasistatic_box_descent(*[dev.to_dev(a) for a in (At, Bt, ct, Q, Qd, R, xd, x0)], *rows_d,
+                                   solver=0, max_iter=2000, eps=1e-10)
+    info = o["info"].cpu().numpy()
+    assert info[0] == 0 and info[2] == 0, info
+    np.testing.assert_allclose(o["u_new"].cpu().numpy(), ua, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(o["x_new"].cpu().numpy(), xa, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(float(o["cost"].item()), orc.eval_cost_quasistatic(xa, ua, xd, Q, Qd, R, idx),
+                               rtol=1e-9)
+    if kind == "none":
+        # no bounds: the tail re-solves collapse to the du-cost Riccati policy of the augmented LQR
+        Ab, Bb, cb, Qb, Qdb, xdb = orc.quasistatic_augment(At, Bt, ct, Q, Qd, xd)
+        K, k = orc.tvlqr_riccati(Ab, Bb, cb, Qb, Qdb, R, xdb, alpha_R=1.0)
+        x = x0.copy()
+        for t in range(T):
+            z = np.concatenate([x, x[idx]])
+            u = z[7:] + K[t] @ z + k[t]
+            np.testing.assert_allclose(ua[t], u, rtol=0, atol=1e-9)
+            x = sys_o.dynamics(x, u)
