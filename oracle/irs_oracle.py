@@ -363,10 +363,12 @@ class PlanarHandOracle:
         r = phi - np.einsum("bik,k,bk->bi", J, Dinv, b)
         lam = np.zeros_like(r)
         invW = 1.0 / np.einsum("bii->bi", W)
+        g = r.copy()                               # residual g = r + W lam, kept up to date
         for _ in range(int(self.pgs_iters)):
             for i in range(8):
-                acc = r[:, i] + np.einsum("bj,bj->b", W[:, i], lam)
-                lam[:, i] = np.maximum(lam[:, i] - acc * invW[:, i], 0.0)
+                new = np.maximum(lam[:, i] - g[:, i] * invW[:, i], 0.0)
+                g += W[:, :, i] * (new - lam[:, i])[:, None]
+                lam[:, i] = new
         return np.atleast_2d(x) + (np.einsum("bik,bi->bk", J, lam) - b) * Dinv
 
     def dynamics(self, x, u):
