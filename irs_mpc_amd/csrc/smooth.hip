@@ -35,6 +35,15 @@ namespace {
 constexpr int kBlock = 256;
 
 constexpr int kCounterBytes = 4096;   // head of the workspace: arrival counters
+// then T rows of f64 nominal steps (n <= 32)
+constexpr size_t fnom_bytes(int T) { return (size_t)T * 32 * sizeof(double); }
+
+// models whose step is expensive and has no Jacobian (contact QPs): in the fused launch workgroup
+// 0 of every timestep takes fewer samples and evaluates the f64 nominal step the solve needs while
+// the other workgroups are still sampling, instead of the last arriver doing it serially
+template <class Model, int MODE>
+constexpr bool nominal_in_wg0() { return !Model::HAS_JACOBIAN && MODE != IRS_SMOOTH_FIRST_ORDER; }
+constexpr int kNominalCost = 3;      // the f64 nominal step costs about this many f32 sample evaluations
 
 template <class Model, int MODE>
 struct SmoothTraits {
@@ -65,6 +74,8 @@ struct SmoothArgs {
     int diag;          // tuning experiments only (IRS_DIAG): 1 = skip the fused solve
     int* counters;     // (T) arrival counters, zero between calls
     float* partial;    // (T, nblk, P)
+    double* fnom;      // (T, n) f64 nominal steps written by workgroup 0 when chunk0 < chunk
+    int chunk0;        // samples of workgroup 0 (== chunk unless it also evaluates the nominal step)
     double* sums;      // (T, P) out
     // finalize outputs (fused path only)
     double* At;
@@ -130,9 +141,20 @@ template <class Model, int MODE>
 __device__ __forceinline__ void finalize_timestep(const ModelParams& p, const double* x_trj,
                                                   const double* u_trj, const double* S, double n_total,
                                                   int t, int lane, FinalizeLds<Model, MODE>& L,
-                                                  double* At, double* Bt, double* ct, int* info) {
+                                                  double* At, double* Bt, double* ct, int* info,
+                                                  const double* fnom = nullptr) {
     using TR = SmoothTraits<Model, MODE>;
     constexpr int n = TR::n, m = TR::m, d = TR::d, NZ = TR::NZ, Z0 = TR::Z0;
+    // f(x_t, u_t) in f64: evaluated here, or -- for models whose step is expensive (contact QPs) --
+    // already evaluated by workgroup 0 of the fused launch, which takes fewer samples in exchange
+    auto nominal = [&](const double* x, const double* u, double* f) {
+        if (fnom != nullptr) {
+#pragma unroll
+            for (int i = 0; i < n; ++i) f[i] = fnom[i];
+        } else {
+            Model::template step<double>(p, x, u, f);
+        }
+    };
 
     double x[n], u[m], f[n];
 #pragma unroll
@@ -159,7 +181,7 @@ __device__ __forceinline__ void finalize_timestep(const ModelParams& p, const do
             } else {
                 // decouple_AB (irs_lqr_quasistatic.py:275-284): A = I with the actuated
                 // columns zeroed (the actuated rows of B become I after the fit, below)
-                Model::template step<double>(p, x, u, f);
+                nominal(x, u, f);
                 for (int q = lane; q < n * n; q += 64) {
                     int i = q / n, k = q % n;
                     bool act = false;
@@ -168,7 +190,7 @@ __device__ __forceinline__ void finalize_timestep(const ModelParams& p, const do
                 }
             }
         } else {
-            Model::template step<double>(p, x, u, f);
+            nominal(x, u, f);
         }
         if constexpr (NZ <= 4) {
             // tiny system: every lane solves it in registers (no LDS round trips)
@@ -342,7 +364,10 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
     for (int j = 0; j < m; ++j) ub[j] = (float)a.u_trj[(size_t)t * m + j];
     if constexpr (MODE != IRS_SMOOTH_FIRST_ORDER) Model::template step<float>(a.p, xb, ub, f0);
 
-    const int s_end = min(a.N, (blk + 1) * a.chunk);
+    // workgroup 0 owns [0, chunk0), workgroup b >= 1 owns chunk0 + [(b-1) chunk, b chunk)
+    const int s_begin = blk == 0 ? 0 : a.chunk0 + (blk - 1) * a.chunk;
+    const int s_end = min(a.N, blk == 0 ? a.chunk0 : a.chunk0 + blk * a.chunk);
+    constexpr bool NB = FUSE && nominal_in_wg0<Model, MODE>();
     if constexpr (USE_MFMA) {
         // ---- matrix-core Gram accumulation (zero-order, d <= 16, many statistics) -------
         // The P = d(d+1)/2 + d n statistics are the products Z'Z and Z'dF over the sample
@@ -357,7 +382,7 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
         const int lane = tid & 63, wave = tid >> 6, col = lane & 15, rg = lane >> 4;
         float* my = tile + wave * 64 * TS;
         v4f aG = {0.f, 0.f, 0.f, 0.f}, aH = {0.f, 0.f, 0.f, 0.f};
-        for (int s0 = blk * a.chunk + wave * 64; s0 < s_end; s0 += BLOCK) {
+        for (int s0 = s_begin + wave * 64; s0 < s_end; s0 += BLOCK) {
             const int s = s0 + lane;
             const bool valid = s < s_end;
             float z[16], dfp[16];
@@ -420,7 +445,7 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
         // flight), then evaluated; out-of-range slots are clamped to a valid address and
         // zeroed (a zero perturbation contributes exactly nothing to the zero-order sums).
         constexpr int U = (TR::LIGHT && !RNG) ? 4 : 1;
-        for (int s0 = blk * a.chunk + tid; s0 < s_end; s0 += BLOCK * U) {
+        for (int s0 = s_begin + tid; s0 < s_end; s0 += BLOCK * U) {
             float zz[U][d];
             bool valid[U];
 #pragma unroll
@@ -487,6 +512,21 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
 
         // ---- workgroup reduction: registers -> shuffles -> LDS ---------------------
         block_reduce_lds<P, NW>(acc, red);
+    }
+    if constexpr (NB) {
+        if (blk == 0 && a.chunk0 != a.chunk && tid < 64) {
+            double x64[n], u64[m], f64[n];
+#pragma unroll
+            for (int i = 0; i < n; ++i) x64[i] = a.x_trj[(size_t)t * n + i];
+#pragma unroll
+            for (int j = 0; j < m; ++j) u64[j] = a.u_trj[(size_t)t * m + j];
+            Model::template step<double>(a.p, x64, u64, f64);
+            if (tid == 0) {
+#pragma unroll
+                for (int i = 0; i < n; ++i)
+                    __hip_atomic_store(a.fnom + (size_t)t * n + i, f64[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
     __syncthreads();
 
@@ -567,7 +607,8 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
     if constexpr (FUSE) {
         if (tid < 64 && a.diag != 1)
             finalize_timestep<Model, MODE>(a.p, a.x_trj, a.u_trj, tot, a.n_total, t, tid, fin, a.At, a.Bt,
-                                           a.ct, a.info);
+                                           a.ct, a.info,
+                                           (NB && a.chunk0 != a.chunk) ? a.fnom + (size_t)t * n : nullptr);
     }
 }
 
@@ -703,6 +744,12 @@ bool is_light(int model, int mode) {
     return false;
 }
 
+bool has_nominal_in_wg0(int model, int mode) {
+    bool r = false;
+    IRS_DISPATCH_MODEL(model, { r = !Model::HAS_JACOBIAN && mode != IRS_SMOOTH_FIRST_ORDER; });
+    return r;
+}
+
 template <class Model>
 int sums_len_m(int mode) {
     switch (mode) {
@@ -788,9 +835,22 @@ int smooth_common(int model, const double* params, int n_params, int mode, int T
     a.x_trj = x_trj; a.u_trj = u_trj;
     a.T = T; a.N = N;
     plan_grid(T, N, is_light(model, mode), rng, &a.chunk, &a.nblk, &a.block);
+    a.chunk0 = a.chunk;
+    if (out != nullptr && a.nblk >= 2 && a.block == kBlock && has_nominal_in_wg0(model, mode)) {
+        // workgroup 0 gives up kNominalCost samples per lane and evaluates the f64 nominal step
+        int c0 = a.chunk - kNominalCost * kBlock;
+        if (c0 < kBlock) c0 = kBlock;
+        int rest = (N - c0 + (a.nblk - 1) - 1) / (a.nblk - 1);
+        rest = (rest + kBlock - 1) / kBlock * kBlock;
+        if (c0 < a.chunk && c0 + (long long)(a.nblk - 1) * rest >= N && rest <= a.chunk + kBlock) {
+            a.chunk0 = c0;
+            a.chunk = rest;
+        }
+    }
     { static int dg = getenv("IRS_DIAG") ? atoi(getenv("IRS_DIAG")) : 0; a.diag = dg; }
     a.counters = static_cast<int*>(workspace);
-    a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + kCounterBytes);
+    a.fnom = reinterpret_cast<double*>(static_cast<char*>(workspace) + kCounterBytes);
+    a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + kCounterBytes + fnom_bytes(T));
     a.sums = sums;
     const bool fuse = out != nullptr;
     if (fuse) {
@@ -847,7 +907,7 @@ size_t irs_smooth_workspace_bytes(int model, int mode, int T, int N) {
     if (P <= 0 || T <= 0 || N <= 0) return 0;
     int chunk, nblk, block;
     plan_grid(T, N, is_light(model, mode), /*rng=*/true, &chunk, &nblk, &block);   // the larger grid
-    return kCounterBytes + (size_t)T * nblk * ((P + 3) / 4 * 4) * sizeof(float);
+    return kCounterBytes + fnom_bytes(T) + (size_t)T * nblk * ((P + 3) / 4 * 4) * sizeof(float);
 }
 
 int irs_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
