@@ -64,9 +64,10 @@ struct CbLayout {
     static constexpr int oP = 0, op = oP + NS * NS, oK = op + NS, ok = oK + M * NS, oH = ok + M,
                          oG = oH + M * M, og = oG + M * NS, oA = og + M, oB = oA + NR * NR,
                          oc = oB + NR * M, os = oc + NR, ou = os + NS, ous = ou + M, omu = ous + M,
-                         oact = omu + M, olo = oact + M, ohi = olo + M, S = ohi + M;
-    static constexpr int scratch = 2 * NS * NS + 3 * M * NS + 4 * NS + 3 * M * M + M * (NS + 1) +
-                                   2 * NR * NR + 64;
+                         oact = omu + M, olo = oact + M, ohi = olo + M, oqsd = ohi + M, S = oqsd + NR;
+    static constexpr int NTRI = NS * (NS + 1) / 2;
+    static constexpr int scratch = NS * NR + 2 * M * NS + 4 * NS + 2 * M * M + M * (NS + 1) + 2 * NR * NR +
+                                   NTRI + 64;
     static __host__ __device__ size_t doubles(int T) { return (size_t)(T + 1) * S + scratch; }
 };
 
@@ -74,46 +75,31 @@ template <class Model, int KIND>
 __global__ __launch_bounds__(64) void ctrlbox_descent_kernel(BoxArgs a) {
     constexpr int NR = Model::NX, M = Model::NU, NS = NR + M;
     constexpr double INF = __builtin_huge_val();
+    static_assert(M * (NS + 1) <= 64 && M * NS + M <= 64, "one wave computes [K | k] in a single pass");
     using L = CbLayout<NR, M>;
     extern __shared__ double lds[];
     const int T = a.T, lane = threadIdx.x;
     double* F = lds;
-    double* PB = F + (size_t)(T + 1) * L::S;           // NS x M
-    double* Wm = PB + NS * M;                          // NS x NS
-    double* Pn = Wm + NS * NS;                         // NS x NS
-    double* Y = Pn + NS * NS;                          // M x NS
+    double* PB = F + (size_t)(T + 1) * L::S;           // NS x M    P B_
+    double* WA = PB + NS * M;                          // NS x NR   P[:, :NR] A
+    double* Y = WA + NS * NR;                          // M x NS
     double* qv = Y + M * NS;                           // NS
     double* hk = qv + NS;                              // M (padded NS)
     double* Hm = hk + NS;                              // M x M
-    double* Hinv = Hm + M * M;                         // M x M
-    double* RHS = Hinv + M * M;                        // M x (NS+1)
+    double* RHS = Hm + M * M;                          // M x (NS+1)
     double* Qsym = RHS + M * (NS + 1);                 // NR x NR
     double* Qdsym = Qsym + NR * NR;                    // NR x NR
     double* Rsym = Qdsym + NR * NR;                    // M x M
     double* sstart = Rsym + M * M;                     // NS
+    int* tri = reinterpret_cast<int*>(sstart + NS);    // (i << 8 | j), i <= j, of the upper triangle
 
     auto rec_ = [&](int t) -> double* { return F + (size_t)t * L::S; };
     // problem data of the LQR in s = [x; w]
-    auto A_ = [&](const double* rec, int i, int j) -> double {
-        if (i < NR) {
-            if (j < NR) return rec[L::oA + i * NR + j];
-            return KIND == KIND_REL ? rec[L::oB + i * M + (j - NR)] : 0.0;
-        }
-        return (KIND == KIND_REL && i == j) ? 1.0 : 0.0;
-    };
-    auto B_ = [&](const double* rec, int i, int j) -> double {
-        return i < NR ? rec[L::oB + i * M + j] : ((i - NR) == j ? 1.0 : 0.0);
-    };
     auto Qs_ = [&](int i, int j) -> double {
         if (i < NR && j < NR) return Qsym[i * NR + j];
         if (KIND == KIND_ABS && i >= NR && j >= NR) return Rsym[(i - NR) * M + (j - NR)];
         return 0.0;
     };
-    auto Nc_ = [&](int i, int j) -> double {          // NS x M
-        return (KIND == KIND_ABS && i >= NR) ? -Rsym[(i - NR) * M + j] : 0.0;
-    };
-    auto sd_ = [&](int t, int i) -> double { return i < NR ? a.xd[(size_t)t * NR + i] : 0.0; };
-
     // ---- setup ------------------------------------------------------------------------
     for (int q = lane; q < NR * NR; q += 64) {
         int i = q / NR, j = q % NR;
@@ -124,6 +110,12 @@ __global__ __launch_bounds__(64) void ctrlbox_descent_kernel(BoxArgs a) {
         int i = q / M, j = q % M;
         Rsym[q] = 0.5 * (a.R[i * M + j] + a.R[j * M + i]);
     }
+    for (int q = lane; q < L::NTRI; q += 64) {
+        int i = 0, r = q;
+        while (r >= NS - i) { r -= NS - i; ++i; }
+        tri[q] = (i << 8) | (i + r);
+    }
+    wave_sync();
     const double* blo = KIND == KIND_ABS ? a.ulo : a.dlo;
     const double* bhi = KIND == KIND_ABS ? a.uhi : a.dhi;
     const int bs = KIND == KIND_ABS ? a.su : a.sd;
@@ -131,7 +123,12 @@ __global__ __launch_bounds__(64) void ctrlbox_descent_kernel(BoxArgs a) {
         double* rec = rec_(t);
         for (int q = lane; q < NR * NR; q += 64) rec[L::oA + q] = a.At[(size_t)t * NR * NR + q];
         for (int q = lane; q < NR * M; q += 64) rec[L::oB + q] = a.Bt[(size_t)t * NR * M + q];
-        if (lane < NR) rec[L::oc + lane] = a.ct[(size_t)t * NR + lane];
+        if (lane < NR) {
+            rec[L::oc + lane] = a.ct[(size_t)t * NR + lane];
+            double sq = 0.0;
+            for (int j = 0; j < NR; ++j) sq += Qsym[lane * NR + j] * a.xd[(size_t)t * NR + j];
+            rec[L::oqsd + lane] = sq;                  // (Qs sd_t)[:NR]; the w block of sd is zero
+        }
         if (lane < M) {
             rec[L::olo + lane] = blo ? blo[(size_t)t * bs + lane] : -INF;
             rec[L::ohi + lane] = bhi ? bhi[(size_t)t * bs + lane] : INF;
@@ -164,72 +161,94 @@ __global__ __launch_bounds__(64) void ctrlbox_descent_kernel(BoxArgs a) {
         const double* nxt = rec_(t + 1);
         const double* P = nxt + L::oP;
         const double* p = nxt + L::op;
-        // PB = P B_ ; qv = P c_ + p
+        const double* A = rec + L::oA;                 // NR x NR
+        const double* B = rec + L::oB;                 // NR x M
+        // The block structure of A_ = [[A, B or 0], [0, I or 0]] and B_ = [B; I] is used throughout:
+        // every product below is a length-NR contraction plus at most one extra term.
+        // ---- phase 1: WA = P[:, :NR] A ; PB = P B_ ; qv = P c_ + p
+        for (int q = lane; q < NS * NR; q += 64) {
+            const int i = q / NR, j = q % NR;
+            double s = 0.0;
+#pragma unroll
+            for (int l = 0; l < NR; ++l) s += P[i * NS + l] * A[l * NR + j];
+            WA[q] = s;
+        }
         for (int q = lane; q < NS * M; q += 64) {
-            int i = q / M, j = q % M;
+            const int i = q / M, j = q % M;
             double s = P[i * NS + NR + j];
-            for (int l = 0; l < NR; ++l) s += P[i * NS + l] * rec[L::oB + l * M + j];
+#pragma unroll
+            for (int l = 0; l < NR; ++l) s += P[i * NS + l] * B[l * M + j];
             PB[q] = s;
         }
         if (lane < NS) {
             double s = p[lane];
+#pragma unroll
             for (int l = 0; l < NR; ++l) s += P[lane * NS + l] * rec[L::oc + l];
             qv[lane] = s;
         }
-        // W = P A_
-        for (int q = lane; q < NS * NS; q += 64) {
-            int i = q / NS, j = q % NS;
-            double s = 0.0;
-            for (int l = 0; l < NS; ++l) s += P[i * NS + l] * A_(rec, l, j);
-            Wm[q] = s;
+        wave_sync();
+        // ---- phase 2, one pass, one code shape: H = Ru + B_'PB (M*M items), g = B_'qv (M items),
+        //      G[:, :NR] = PB[:NR]'A (M*NR items):  dst = extra + sum_{l<NR} X[l sx] Y[l sy]
+        {
+            static_assert(M * M + M + M * NR <= 64, "phase 2 is a single pass");
+            const double *X = B, *Yp = PB;
+            int sx = 0, sy = 0;
+            double extra = 0.0;
+            double* dst = nullptr;
+            if (lane < M * M) {
+                const int i = lane / M, j = lane % M;
+                X = B + i; sx = M; Yp = PB + j; sy = M;
+                extra = Rsym[lane] + PB[(NR + i) * M + j];
+                dst = rec + L::oH + lane;
+            } else if (lane < M * M + M) {
+                const int i = lane - M * M;
+                X = B + i; sx = M; Yp = qv; sy = 1;
+                extra = qv[NR + i];
+                dst = rec + L::og + i;
+            } else if (lane < M * M + M + M * NR) {
+                const int q = lane - (M * M + M), i = q / NR, j = q % NR;
+                X = PB + i; sx = M; Yp = A + j; sy = NR;
+                dst = rec + L::oG + i * NS + j;
+            }
+            double s = extra;
+#pragma unroll
+            for (int l = 0; l < NR; ++l) s += X[l * sx] * Yp[l * sy];
+            if (dst) *dst = s;
         }
         wave_sync();
-        // H = Ru + B_'PB ; g = B_'qv ; G = PB'A_ + Nc'
+        // ---- phase 3: G[:, NR:] (= H' - Ru for REL, -Ru for ABS), masked system
+        auto Ghi = [&](int i, int j) -> double {      // G[i][NR + j]
+            return KIND == KIND_REL ? rec[L::oH + j * M + i] - Rsym[j * M + i] : -Rsym[i * M + j];
+        };
         for (int q = lane; q < M * M; q += 64) {
-            int i = q / M, j = q % M;
-            double s = Rsym[q] + PB[(NR + i) * M + j];
-            for (int l = 0; l < NR; ++l) s += rec[L::oB + l * M + i] * PB[l * M + j];
-            rec[L::oH + q] = s;
-        }
-        if (lane < M) {
-            double s = qv[NR + lane];
-            for (int l = 0; l < NR; ++l) s += rec[L::oB + l * M + lane] * qv[l];
-            rec[L::og + lane] = s;
-        }
-        for (int q = lane; q < M * NS; q += 64) {
-            int i = q / NS, j = q % NS;
-            double s = Nc_(j, i);
-            for (int l = 0; l < NS; ++l) s += PB[l * M + i] * A_(rec, l, j);
-            rec[L::oG + q] = s;
-        }
-        wave_sync();
-        // masked system: pinned rows/columns of H replaced by the identity
-        for (int q = lane; q < M * M; q += 64) {
-            int i = q / M, j = q % M;
+            const int i = q / M, j = q % M;
+            rec[L::oG + i * NS + NR + j] = Ghi(i, j);
             const bool fi = rec[L::oact + i] == 0.0, fj = rec[L::oact + j] == 0.0;
             Hm[q] = (fi && fj) ? rec[L::oH + q] : (i == j ? 1.0 : 0.0);
         }
         for (int q = lane; q < M * (NS + 1); q += 64) {
-            int i = q / (NS + 1), j = q % (NS + 1);
+            const int i = q / (NS + 1), j = q % (NS + 1);
             const double ai = rec[L::oact + i];
-            const double ubar = ai < 0.0 ? rec[L::olo + i] : rec[L::ohi + i];
             double s;
             if (ai == 0.0) {
-                if (j < NS) s = -rec[L::oG + i * NS + j];
+                if (j < NR) s = -rec[L::oG + i * NS + j];
+                else if (j < NS) s = -Ghi(i, j - NR);
                 else {
                     s = -rec[L::og + i];
+#pragma unroll
                     for (int l = 0; l < M; ++l) {
                         const double al = rec[L::oact + l];
-                        if (al != 0.0) s -= rec[L::oH + i * M + l] * (al < 0.0 ? rec[L::olo + l] : rec[L::ohi + l]);
+                        const double ubl = al < 0.0 ? rec[L::olo + l] : rec[L::ohi + l];
+                        s -= al != 0.0 ? rec[L::oH + i * M + l] * ubl : 0.0;
                     }
                 }
             } else {
-                s = j < NS ? 0.0 : ubar;
+                s = j < NS ? 0.0 : (ai < 0.0 ? rec[L::olo + i] : rec[L::ohi + i]);
             }
             RHS[q] = s;
         }
         wave_sync();
-        // Hm^-1 by LDL' in registers (every lane), lane j < M keeps column j
+        // ---- phase 4: Hm^-1 by LDL' in registers (every lane); lane q computes entry q of [K | k]
         {
             double Lm[M][M], Dg[M], Dinv[M];
 #pragma unroll
@@ -248,72 +267,82 @@ __global__ __launch_bounds__(64) void ctrlbox_descent_kernel(BoxArgs a) {
                     Lm[i][j] = s * Dinv[j];
                 }
             }
-            if (lane < M) {
-                double y[M];
+            const int q = lane < M * (NS + 1) ? lane : 0;
+            const int col = q / (NS + 1), j = q % (NS + 1);
+            double y[M];                               // column `col` of Hm^-1 (= its row: symmetric)
 #pragma unroll
-                for (int i = 0; i < M; ++i) {
-                    double s = (i == lane) ? 1.0 : 0.0;
+            for (int i = 0; i < M; ++i) {
+                double s = (i == col) ? 1.0 : 0.0;
 #pragma unroll
-                    for (int l = 0; l < i; ++l) s -= Lm[i][l] * y[l];
-                    y[i] = s;
-                }
+                for (int l = 0; l < i; ++l) s -= Lm[i][l] * y[l];
+                y[i] = s;
+            }
 #pragma unroll
-                for (int i = M - 1; i >= 0; --i) {
-                    double s = y[i] * Dinv[i];
+            for (int i = M - 1; i >= 0; --i) {
+                double s = y[i] * Dinv[i];
 #pragma unroll
-                    for (int l = i + 1; l < M; ++l) s -= Lm[l][i] * y[l];
-                    y[i] = s;
-                }
+                for (int l = i + 1; l < M; ++l) s -= Lm[l][i] * y[l];
+                y[i] = s;
+            }
+            if (lane < M * (NS + 1)) {
+                double s = 0.0;
 #pragma unroll
-                for (int i = 0; i < M; ++i) Hinv[i * M + lane] = y[i];
+                for (int l = 0; l < M; ++l) s += y[l] * RHS[l * (NS + 1) + j];
+                if (j < NS) rec[L::oK + col * NS + j] = s;
+                else rec[L::ok + col] = s;
             }
         }
         wave_sync();
-        // [K | k] = Hm^-1 RHS
-        for (int q = lane; q < M * (NS + 1); q += 64) {
-            int i = q / (NS + 1), j = q % (NS + 1);
+        // ---- phase 5: Y = H K + G ; hk = H k + g
+        if (lane < M * NS) {
+            const int i = lane / NS;
+            double s = rec[L::oG + lane];
+#pragma unroll
+            for (int l = 0; l < M; ++l) s += rec[L::oH + i * M + l] * rec[L::oK + l * NS + lane % NS];
+            Y[lane] = s;
+        } else if (lane < M * NS + M) {
+            const int i = lane - M * NS;
+            double s = rec[L::og + i];
+#pragma unroll
+            for (int l = 0; l < M; ++l) s += rec[L::oH + i * M + l] * rec[L::ok + l];
+            hk[i] = s;
+        }
+        wave_sync();
+        // ---- phase 6: upper triangle of P_t = Qs + A_'W + K'Y + G'K (mirrored on store) and
+        //      p_t = -Qs sd_t + A_'qv + K'hk + G'k, with W = P A_ = [WA | PB or 0]
+        for (int it = lane; it < L::NTRI + NS; it += 64) {
+            const bool isP = it < L::NTRI;
+            const int i = isP ? (tri[it] >> 8) : it - L::NTRI;
+            const int j = isP ? (tri[it] & 255) : 0;
+            // column i of A_ restricted to its first NR rows, and whether A_[i][i] = 1 (REL, i >= NR)
+            const double* Xc = i < NR ? A + i : B + (i - NR);
+            const int sx = i < NR ? NR : M;
+            const double xz = (i < NR || KIND == KIND_REL) ? 1.0 : 0.0;
+            const bool diag = KIND == KIND_REL && i >= NR;
+            // column j of W (or qv for the p row)
+            const double* Wc = !isP ? qv : (j < NR ? WA + j : PB + (j - NR));
+            const int sw = !isP ? 1 : (j < NR ? NR : M);
+            const double wz = (!isP || j < NR || KIND == KIND_REL) ? 1.0 : 0.0;
             double s = 0.0;
-            for (int l = 0; l < M; ++l) s += Hinv[i * M + l] * RHS[l * (NS + 1) + j];
-            if (j < NS) rec[L::oK + i * NS + j] = s;
-            else rec[L::ok + i] = s;
-        }
-        wave_sync();
-        // Y = H K + G ; hk = H k + g
-        for (int q = lane; q < M * NS; q += 64) {
-            int i = q / NS, j = q % NS;
-            double s = rec[L::oG + q];
-            for (int l = 0; l < M; ++l) s += rec[L::oH + i * M + l] * rec[L::oK + l * NS + j];
-            Y[q] = s;
-        }
-        if (lane < M) {
-            double s = rec[L::og + lane];
-            for (int l = 0; l < M; ++l) s += rec[L::oH + lane * M + l] * rec[L::ok + l];
-            hk[lane] = s;
-        }
-        wave_sync();
-        // P_t = sym(Qs + A_'W + K'Y + G'K) ; p_t = -Qs sd_t + A_'qv + K'hk + G'k
-        for (int q = lane; q < NS * NS; q += 64) {
-            int i = q / NS, j = q % NS;
-            double s = 0.0, s2 = 0.0;
-            for (int l = 0; l < NS; ++l) {
-                s += A_(rec, l, i) * Wm[l * NS + j];
-                s2 += A_(rec, l, j) * Wm[l * NS + i];
+#pragma unroll
+            for (int l = 0; l < NR; ++l) s += Xc[l * sx] * Wc[l * sw];
+            if (diag) s += Wc[i * sw];
+            s *= xz * wz;
+            if (isP) {
+#pragma unroll
+                for (int l = 0; l < M; ++l)
+                    s += rec[L::oK + l * NS + i] * Y[l * NS + j] + rec[L::oG + l * NS + i] * rec[L::oK + l * NS + j];
+                s += Qs_(i, j);
+                rec[L::oP + i * NS + j] = s;
+                rec[L::oP + j * NS + i] = s;
+            } else {
+#pragma unroll
+                for (int l = 0; l < M; ++l)
+                    s += rec[L::oK + l * NS + i] * hk[l] + rec[L::oG + l * NS + i] * rec[L::ok + l];
+                if (i < NR) s -= rec[L::oqsd + i];
+                rec[L::op + i] = s;
             }
-            for (int l = 0; l < M; ++l) {
-                s += rec[L::oK + l * NS + i] * Y[l * NS + j] + rec[L::oG + l * NS + i] * rec[L::oK + l * NS + j];
-                s2 += rec[L::oK + l * NS + j] * Y[l * NS + i] + rec[L::oG + l * NS + j] * rec[L::oK + l * NS + i];
-            }
-            Pn[q] = Qs_(i, j) + 0.5 * (s + s2);
         }
-        if (lane < NS) {
-            double s = 0.0;
-            for (int j = 0; j < NS; ++j) s -= Qs_(lane, j) * sd_(t, j);
-            for (int l = 0; l < NS; ++l) s += A_(rec, l, lane) * qv[l];
-            for (int l = 0; l < M; ++l) s += rec[L::oK + l * NS + lane] * hk[l] + rec[L::oG + l * NS + lane] * rec[L::ok + l];
-            rec[L::op + lane] = s;
-        }
-        wave_sync();
-        for (int q = lane; q < NS * NS; q += 64) rec[L::oP + q] = Pn[q];
         wave_sync();
     };
 
@@ -323,23 +352,35 @@ __global__ __launch_bounds__(64) void ctrlbox_descent_kernel(BoxArgs a) {
         wave_sync();
         for (int t = t0; t < T; ++t) {
             double* rec = rec_(t);
+            const double* sv = rec + L::os;
             if (lane < M) {
                 double s = rec[L::ok + lane];
-                for (int l = 0; l < NS; ++l) s += rec[L::oK + lane * NS + l] * rec[L::os + l];
+#pragma unroll
+                for (int l = 0; l < NS; ++l) s += rec[L::oK + lane * NS + l] * sv[l];
                 rec[dst + lane] = s;
             }
             wave_sync();
+            // s+ = [A x + B u_abs + c ; u_abs] with u_abs the absolute command (ABS: the control
+            // itself, REL: w + v) -- the same expression for both kinds
             if (lane < M) {
                 double s = rec[L::og + lane];
+#pragma unroll
                 for (int l = 0; l < M; ++l) s += rec[L::oH + lane * M + l] * rec[dst + l];
-                for (int l = 0; l < NS; ++l) s += rec[L::oG + lane * NS + l] * rec[L::os + l];
+#pragma unroll
+                for (int l = 0; l < NS; ++l) s += rec[L::oG + lane * NS + l] * sv[l];
                 rec[L::omu + lane] = s;
-            } else if (lane < M + NS) {
+            } else if (lane < M + NR) {
                 const int i = lane - M;
-                double s = i < NR ? rec[L::oc + i] : 0.0;
-                for (int l = 0; l < NS; ++l) s += A_(rec, i, l) * rec[L::os + l];
-                for (int j = 0; j < M; ++j) s += B_(rec, i, j) * rec[dst + j];
+                double s = rec[L::oc + i];
+#pragma unroll
+                for (int l = 0; l < NR; ++l) s += rec[L::oA + i * NR + l] * sv[l];
+#pragma unroll
+                for (int j = 0; j < M; ++j)
+                    s += rec[L::oB + i * M + j] * (rec[dst + j] + (KIND == KIND_REL ? sv[NR + j] : 0.0));
                 rec_(t + 1)[L::os + i] = s;
+            } else if (lane < M + NS) {
+                const int j = lane - M - NR;
+                rec_(t + 1)[L::os + NR + j] = rec[dst + j] + (KIND == KIND_REL ? sv[NR + j] : 0.0);
             }
             wave_sync();
         }
