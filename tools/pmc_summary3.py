@@ -1,0 +1,60 @@
+"""Condenses the rocprofv3 passes of tools/profile_round3.sh into small files for profiles/:
+per-kernel call counts / average durations, and per-kernel averages of every PMC counter."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+out_dir, tag = sys.argv[1], sys.argv[2]
+
+
+def short(name):
+    for key, tag_ in (("smooth_kernelI15PlanarHand", "planar_hand_zeroB_T50_N10000"),
+                      ("smooth_kernelI13Pendulum", "pendulum_zero_T30_N10000"),
+                      ("smooth_kernel<(anonymous namespace)::PlanarHand", "planar_hand_zeroB_T50_N10000"),
+                      ("smooth_kernel<PlanarHand", "planar_hand_zeroB_T50_N10000"),
+                      ("smooth_kernel<Pendulum", "pendulum_zero_T30_N10000"),
+                      ("ctrlbox_descent_kernel", "planar_hand_ctrlbox_descent_T50"),
+                      ("descent_kernel", "pendulum_descent_T30")):
+        if key in name:
+            return tag_
+    if "PlanarHandModel" in name and "smooth_kernel" in name:
+        return "planar_hand_zeroB_T50_N10000"
+    if "PendulumModel" in name and "smooth_kernel" in name:
+        return "pendulum_zero_T30_N10000"
+    return None
+
+
+res = collections.defaultdict(dict)
+lines = []
+f = glob.glob("%s/stats/*/*kernel_stats.csv" % out_dir)
+if f:
+    for r in csv.DictReader(open(f[0])):
+        lines.append("%s,%s,%s,%s,%s" % (r["Name"].replace(",", ";")[:140], r["Calls"], r["AverageNs"], r["MinNs"], r["MaxNs"]))
+        k = short(r["Name"])
+        if k:
+            res[k]["kernel_avg_ns"] = float(r["AverageNs"])
+            res[k]["kernel_calls"] = int(r["Calls"])
+            if "smooth_kernel" in r["Name"]:
+                res[k]["smooth_kernel_avg_ns"] = float(r["AverageNs"])
+for d in sorted(glob.glob("%s/pmc_*" % out_dir)):
+    if not os.path.isdir(d):
+        continue
+    ctr = os.path.basename(d)[4:]
+    f = glob.glob("%s/*/*counter_collection.csv" % d)
+    if not f:
+        continue
+    vals = collections.defaultdict(list)
+    for r in csv.DictReader(open(f[0])):
+        if r.get("Counter_Name") == ctr:
+            vals[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    for name, v in vals.items():
+        k = short(name)
+        if k:
+            res[k][ctr + "_raw_avg"] = sum(v) / len(v)
+            res[k][ctr + "_n"] = len(v)
+json.dump(res, open(os.path.join(out_dir, "pmc_summary.json"), "w"), indent=1)
+open(os.path.join(out_dir, "kernel_stats.csv"), "w").write("kernel,calls,avg_ns,min_ns,max_ns\n" + "\n".join(lines) + "\n")
+print(json.dumps(res, indent=1))
