@@ -164,9 +164,15 @@ def main():
         """W untimed steps, then EXACTLY `steps` steps between barrier+synchronize pairs
         (host clock, max over ranks).  Also returns the same region measured by a HIP
         event pair recorded on the launch stream (device clock)."""
-        t_end = time.perf_counter() + 0.25        # bring the clocks up before the W warmup steps
-        while time.perf_counter() < t_end:
-            fn()
+        # bring the clocks up before the W warmup steps.  Time-based on one GPU; a FIXED count with
+        # several ranks (fn contains a collective: every rank must issue the same number of them)
+        if world == 1:
+            t_end = time.perf_counter() + 0.25
+            while time.perf_counter() < t_end:
+                fn()
+        else:
+            for _ in range(50):
+                fn()
         for _ in range(warmup):
             fn()
         torch.cuda.synchronize()
