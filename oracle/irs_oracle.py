@@ -19,6 +19,13 @@ The QP solver itself (Drake + OSQP, irs_lqr/tv_lqr.py:69-137) is a third-party
 dependency that is not vendored and not installed; solve_tvlqr_qp() below
 restates the QP exactly as posed and solves its KKT system directly (valid while
 the box bounds are inactive), and the two *_exact.csv files anchor it.
+
+PARITY UNPINNED for the quasistatic part (PlanarHandOracle and the *_quasistatic / ctrlbox_*
+functions): the reference steps pangtao22/quasistatic_simulator (external, not vendored, model
+files absent; plus Drake and Gurobi), so the contact step restates the published scheme
+(Anitescu's convex quasi-dynamic step) on the constants the reference does state, and the
+bounded du-cost QPs of irs_lqr/tv_lqr.py:96-127 are certified against their own KKT conditions
+instead of a reference run.  See DESIGN.md section 3.
 """
 import numpy as np
 
