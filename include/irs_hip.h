@@ -276,6 +276,15 @@ int irs_cem_rollout_costs(int model, const double *params, int n_params, int T, 
                           const double *u_cand, const double *x0, const double *Q,
                           const double *R, const double *xd_trj, double *costs, void *stream);
 
+/* Steps 1-2 of CrossEntropyMethodQuasistatic.local_descent (irs_lqr/cem_quasistatic.py:186-200)
+ * for a position-controlled model: as irs_cem_rollout_costs, but every candidate is priced with
+ * the quasistatic eval_cost (:124-165): state error with Q, TERMINAL Qd, input cost on
+ * u_t - u_{t-1} (u_{-1} = x_0[indices_u_into_x]).                                              */
+int irs_cem_rollout_costs_quasistatic(int model, const double *params, int n_params, int T, int B,
+                                      const double *u_cand, const double *x0, const double *Q,
+                                      const double *Qd, const double *R, const double *xd_trj,
+                                      double *costs, void *stream);
+
 /* Steps 3-4 (cem.py:173-180): the n_elite cheapest candidates (np.argpartition) ->
  * elite_idx (n_elite) DEV int32 (cheaper-than-threshold candidates in increasing index
  * order, then threshold ties, lowest index first: deterministic), their mean -> u_new (T,m) and

@@ -1,6 +1,8 @@
 """irs_mpc_amd -- MI355X-native iRS-LQR inner loop (drop-in for the smoothing +
 TV-LQR hot path of hjsuh94/irs_mpc).  See DESIGN.md."""
 from .cem import CemParameters, CrossEntropyMethod                  # noqa: F401
+from .cem_quasistatic import (CemQuasistaticParameters,            # noqa: F401
+                              CrossEntropyMethodQuasistatic)
 from .dynamical_system import DynamicalSystem                       # noqa: F401
 from .irs_lqr import (IrsLqr, IrsLqrExact, IrsLqrFirstOrder,        # noqa: F401
                       IrsLqrParameters, IrsLqrZeroOrder)

@@ -84,6 +84,8 @@ class DescentCall(ctypes.Structure):
 
 SIGNATURES["irs_cem_rollout_costs"] = (c_int, [c_int, POINTER(c_double), c_int, c_int, c_int, _dp, _dp, _dp, _dp,
                                                _dp, _dp, c_void_p])
+SIGNATURES["irs_cem_rollout_costs_quasistatic"] = (c_int, [c_int, POINTER(c_double), c_int, c_int, c_int, _dp, _dp, _dp,
+                                                           _dp, _dp, _dp, _dp, c_void_p])
 SIGNATURES["irs_cem_refit"] = (c_int, [c_int, c_int, c_int, c_int, _dp, _dp, _dp, _dp, _dp, c_void_p])
 SIGNATURES["irs_tvlqr_box_descent"] = (c_int, [c_int, POINTER(c_double), c_int, c_int, _dp, _dp, _dp, _dp, _dp, _dp,
                                                c_double, _dp, _dp, _dp, _dp, _dp, _dp, c_double, c_double, c_int,

@@ -8,7 +8,7 @@
 //   4. roll out the mean (:182)                          -> rollout_kernel (tvlqr.hip)
 // All arithmetic in f64: rollout costs only rank the candidates, but ties broken by f32
 // noise would change the elite set and hence the refit.
-#include "irs_common.hpp"
+#include "boxqp.hpp"      // has_u_into_x
 
 namespace {
 
@@ -55,6 +55,65 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(ModelParams p, int T, 
 #pragma unroll
             for (int j = 0; j < m; ++j) r += Rs[i * m + j] * u[j];
             cost += u[i] * r;
+        }
+        Model::template step<double>(p, x, u, xn);
+#pragma unroll
+        for (int i = 0; i < n; ++i) x[i] = xn[i];
+    }
+    costs[b] = cost;
+}
+
+// CrossEntropyMethodQuasistatic.local_descent steps 1-2 (irs_lqr/cem_quasistatic.py:186-200): the
+// candidate cost is IrsLqrQuasistatic's eval_cost (:124-165) -- state error with Q, TERMINAL Qd,
+// input cost on du_t = u_t - u_{t-1} with du_0 = u_0 - x_0[indices_u_into_x].
+template <class Model>
+__global__ __launch_bounds__(64) void cem_rollout_quasistatic_kernel(ModelParams p, int T, int B,
+                                                                     const double* __restrict__ u_cand,
+                                                                     const double* __restrict__ x0,
+                                                                     const double* __restrict__ Q,
+                                                                     const double* __restrict__ Qd,
+                                                                     const double* __restrict__ R,
+                                                                     const double* __restrict__ xd_trj,
+                                                                     double* __restrict__ costs) {
+    constexpr int n = Model::NX, m = Model::NU;
+    __shared__ double Qs[n * n];
+    __shared__ double Qds[n * n];
+    __shared__ double Rs[m * m];
+    for (int q = threadIdx.x; q < n * n; q += blockDim.x) { Qs[q] = Q[q]; Qds[q] = Qd[q]; }
+    for (int q = threadIdx.x; q < m * m; q += blockDim.x) Rs[q] = R[q];
+    __syncthreads();
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double x[n], u[m], up[m], xn[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) x[i] = x0[i];
+#pragma unroll
+    for (int j = 0; j < m; ++j) up[j] = x0[Model::u_into_x(j)];
+    const double* ub = u_cand + (size_t)b * T * m;
+    double cost = 0.0;
+    for (int t = 0; t <= T; ++t) {
+        const double* xd = xd_trj + (size_t)t * n;
+        const double* W = t == T ? Qds : Qs;
+        double e[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i) e[i] = x[i] - xd[i];
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            double r = 0.0;
+#pragma unroll
+            for (int j = 0; j < n; ++j) r += W[i * n + j] * e[j];
+            cost += e[i] * r;
+        }
+        if (t == T) break;
+        double dv[m];
+#pragma unroll
+        for (int j = 0; j < m; ++j) { u[j] = ub[(size_t)t * m + j]; dv[j] = u[j] - up[j]; up[j] = u[j]; }
+#pragma unroll
+        for (int i = 0; i < m; ++i) {
+            double r = 0.0;
+#pragma unroll
+            for (int j = 0; j < m; ++j) r += Rs[i * m + j] * dv[j];
+            cost += dv[i] * r;
         }
         Model::template step<double>(p, x, u, xn);
 #pragma unroll
@@ -183,6 +242,31 @@ int irs_cem_rollout_costs(int model, const double* params, int n_params, int T, 
         hipLaunchKernelGGL((cem_rollout_kernel<Model>), dim3((B + 255) / 256), dim3(256), 0, st, p, T, B,
                            u_cand, x0, Q, R, xd_trj, costs);
     });
+    IRS_CHECK_LAUNCH();
+    return IRS_OK;
+}
+
+int irs_cem_rollout_costs_quasistatic(int model, const double* params, int n_params, int T, int B,
+                                      const double* u_cand, const double* x0, const double* Q,
+                                      const double* Qd, const double* R, const double* xd_trj, double* costs,
+                                      void* stream) {
+    IRS_CHECK_ARG(T > 0 && B > 0 && u_cand && x0 && Q && Qd && R && xd_trj && costs, "bad argument");
+    ModelParams p;
+    int rc = irs_load_params(model, params, n_params, &p);
+    if (rc != IRS_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = IRS_ERR_UNSUPPORTED;
+    IRS_DISPATCH_MODEL(model, {
+        if constexpr (has_u_into_x<Model>::value) {
+            // one wave per workgroup: the contact step holds hundreds of f64 registers per lane
+            hipLaunchKernelGGL((cem_rollout_quasistatic_kernel<Model>), dim3((B + 63) / 64), dim3(64), 0, st, p,
+                               T, B, u_cand, x0, Q, Qd, R, xd_trj, costs);
+            rc = IRS_OK;
+        } else {
+            irs_set_error("irs_cem_rollout_costs_quasistatic: model %d is not position controlled", model);
+        }
+    });
+    if (rc != IRS_OK) return rc;
     IRS_CHECK_LAUNCH();
     return IRS_OK;
 }

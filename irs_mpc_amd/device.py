@@ -216,6 +216,16 @@ class DeviceModel:
                                              _ptr(costs, F64), _stream()), "irs_cem_rollout_costs")
         return costs
 
+    def cem_rollout_costs_quasistatic(self, u_cand, x0, Q, Qd, R, xd_trj):
+        """costs (B) with the quasistatic eval_cost (du input cost, terminal Qd)."""
+        B, T = u_cand.shape[0], u_cand.shape[1]
+        costs = torch.empty((B,), dtype=F64, device=u_cand.device)
+        check(self.lib.irs_cem_rollout_costs_quasistatic(self.model_id, self._p, self._np, T, B, _ptr(u_cand, F64),
+                                                         _ptr(x0, F64), _ptr(Q, F64), _ptr(Qd, F64), _ptr(R, F64),
+                                                         _ptr(xd_trj, F64), _ptr(costs, F64), _stream()),
+              "irs_cem_rollout_costs_quasistatic")
+        return costs
+
     def cem_refit(self, u_cand, costs, n_elite):
         """Elite selection + mean/std refit: returns elite_idx (n_elite), u_new (T,m), std_new (T,m)."""
         B, T, m = u_cand.shape

@@ -35,6 +35,30 @@ from ._lib import SMOOTH_ZERO_ORDER_B
 from .tv_lqr import get_solver
 
 
+def quasistatic_eval_cost(q_dynamics, x_trj, u_trj, x_trj_d, Q_dict, Qd_dict, R):
+    """irs_lqr_quasistatic.py:153-194 (= cem_quasistatic.py:124-165): the five cost terms
+    (unactuated / actuated, running / final, input-rate), vectorised over time -- O(T n)
+    bookkeeping on trajectories already on the host."""
+    qd = q_dynamics
+    idx = qd.get_u_indices_into_x()
+    e = np.asarray(x_trj, float) - np.asarray(x_trj_d, float)
+
+    def q_cost(models, rows, Q_dict_):
+        c = 0.
+        for model in models:
+            ei = rows[..., qd.position_indices[model]]
+            c += float((ei * np.asarray(Q_dict_[model], float) * ei).sum())
+        return c
+
+    cost_Qu_final = q_cost(qd.models_unactuated, e[-1], Qd_dict)
+    cost_Qa_final = q_cost(qd.models_actuated, e[-1], Qd_dict)
+    cost_Qu = q_cost(qd.models_unactuated, e[:-1], Q_dict)
+    cost_Qa = q_cost(qd.models_actuated, e[:-1], Q_dict)
+    du = np.diff(np.vstack([np.asarray(x_trj)[0, idx][None], np.asarray(u_trj)]), axis=0)
+    cost_R = float(np.einsum("ti,ij,tj->", du, R, du))
+    return cost_Qu, cost_Qu_final, cost_Qa, cost_Qa_final, cost_R
+
+
 class IrsLqrQuasistaticParameters:
     """irs_lqr/irs_lqr_quasistatic.py:12-41."""
 
@@ -180,28 +204,9 @@ class IrsLqrQuasistatic:
         return cost
 
     def eval_cost(self, x_trj, u_trj):
-        """The five cost terms (unactuated / actuated, running / final, input-rate), vectorised
-        over time: they are O(T n) bookkeeping on trajectories already on the host."""
         T = u_trj.shape[0]
         assert T == self.T and x_trj.shape[0] == T + 1
-        qd = self.q_dynamics
-        idx = qd.get_u_indices_into_x()
-        e = np.asarray(x_trj, float) - np.asarray(self.x_trj_d, float)
-
-        def q_cost(models, rows, Q_dict):
-            c = 0.
-            for model in models:
-                ei = rows[..., qd.position_indices[model]]
-                c += float((ei * np.asarray(Q_dict[model], float) * ei).sum())
-            return c
-
-        cost_Qu_final = q_cost(qd.models_unactuated, e[-1], self.Qd_dict)
-        cost_Qa_final = q_cost(qd.models_actuated, e[-1], self.Qd_dict)
-        cost_Qu = q_cost(qd.models_unactuated, e[:-1], self.Q_dict)
-        cost_Qa = q_cost(qd.models_actuated, e[:-1], self.Q_dict)
-        du = np.diff(np.vstack([np.asarray(x_trj)[0, idx][None], np.asarray(u_trj)]), axis=0)
-        cost_R = float(np.einsum("ti,ij,tj->", du, self.R, du))
-        return cost_Qu, cost_Qu_final, cost_Qa, cost_Qa_final, cost_R
+        return quasistatic_eval_cost(self.q_dynamics, x_trj, u_trj, self.x_trj_d, self.Q_dict, self.Qd_dict, self.R)
 
     # ---- linearisation: irs_lqr_quasistatic.py:196-273 ------------------------
     def _get_TV_matrices_dev(self, x_trj, u_trj):

@@ -1182,3 +1182,18 @@ def local_descent_quasistatic_as(system, At, Bt, ct, Q, Qd, R, x0, xd_trj, lo, h
         u_new[t] = ctl if kind == "abs" else s_t[n:] + ctl
         x_new[t + 1] = system.dynamics(x_new[t], u_new[t])
     return x_new, u_new, stats
+
+
+def cem_quasistatic_local_descent(system, x0, u_trj, std_trj, xd_trj, Q, Qd, R, n_elite, batch_size):
+    """irs_lqr/cem_quasistatic.py:168-211: candidates from np.random.normal (global RNG, like the
+    reference), each priced by the quasistatic eval_cost (:124-165), elites by argpartition, refit."""
+    T, m = u_trj.shape
+    idx = system.indices_u_into_x
+    cand = np.random.normal(u_trj, std_trj, (batch_size, T, m))
+    costs = np.zeros(batch_size)
+    for k in range(batch_size):
+        costs[k] = eval_cost_quasistatic(rollout(system, x0, cand[k]), cand[k], xd_trj, Q, Qd, R, idx)
+    best = np.argpartition(costs, n_elite)[:n_elite]
+    u_new = np.mean(cand[best], axis=0)
+    std_new = np.std(cand[best], axis=0)
+    return rollout(system, x0, u_new), u_new, std_new, costs, cand

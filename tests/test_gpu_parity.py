@@ -920,3 +920,38 @@ def test_quasistatic_active_set_full_horizon(amd, kind):
             u = z[7:] + K[t] @ z + k[t]
             np.testing.assert_allclose(ua[t], u, rtol=0, atol=1e-9)
             x = sys_o.dynamics(x, u)
+
+
+def test_cem_quasistatic_vs_oracle(amd):
+    """CrossEntropyMethodQuasistatic (irs_lqr/cem_quasistatic.py:39-258) on the planar hand: identical
+    np.random seeds -> the oracle's candidates, costs, elite refit and trajectory."""
+    T, B, n_elite = 10, 24, 6
+    sys_d, sys_o, x0, u_trj, _, _, _, (Q, Qd, R, xd) = _hand_problem(amd, T, 4, 0)
+    p = amd.CemQuasistaticParameters()
+    q_dict = {"sphere": np.array([1e-3, 1e-3, 10.0]), "arm_left": np.array([1e-3, 1e-3]),
+              "arm_right": np.array([1e-3, 1e-3])}
+    p.Q_dict, p.Qd_dict = q_dict, {k: 100 * v for k, v in q_dict.items()}
+    p.R_dict = {"arm_left": 5 * np.ones(2), "arm_right": 5 * np.ones(2)}
+    p.x0, p.xd_trj, p.u_trj_0, p.T = x0, xd, u_trj, T
+    p.n_elite, p.batch_size, p.initial_std = n_elite, B, 0.05 * np.ones(4)
+    p.publish_every_iteration = False
+    sol = amd.CrossEntropyMethodQuasistatic(sys_d, p)
+    sol.verbose = False
+    np.random.seed(3)
+    xn, un = sol.local_descent(sol.x_trj, sol.u_trj)
+    np.random.seed(3)
+    xo, uo, so, costs, _ = orc.cem_quasistatic_local_descent(sys_o, x0, u_trj, np.tile(p.initial_std, (T, 1)), xd,
+                                                             Q, Qd, R, n_elite, B)
+    np.testing.assert_allclose(sol.cost_array.cpu().numpy(), costs, rtol=1e-10)
+    np.testing.assert_allclose(un, uo, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(sol.std_trj, so, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(xn, xo, rtol=0, atol=1e-9)
+    c0 = sol.cost
+    sol.iterate(2)
+    assert len(sol.cost_all_list) == 4 and sol.cost_best <= c0 and sol.current_iter == 3
+    # the analytic models are not position controlled
+    from irs_mpc_amd import device as dev
+    with pytest.raises(Exception):
+        amd.PendulumDynamics(0.05).dm().cem_rollout_costs_quasistatic(
+            dev.to_dev(np.zeros((4, 3, 1))), dev.to_dev(np.zeros(2)), dev.to_dev(np.eye(2)), dev.to_dev(np.eye(2)),
+            dev.to_dev(np.eye(1)), dev.to_dev(np.zeros((4, 2))))
