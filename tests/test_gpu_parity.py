@@ -955,3 +955,16 @@ def test_cem_quasistatic_vs_oracle(amd):
         amd.PendulumDynamics(0.05).dm().cem_rollout_costs_quasistatic(
             dev.to_dev(np.zeros((4, 3, 1))), dev.to_dev(np.zeros(2)), dev.to_dev(np.eye(2)), dev.to_dev(np.eye(2)),
             dev.to_dev(np.eye(1)), dev.to_dev(np.zeros((4, 2))))
+
+
+@pytest.mark.parametrize("argv", [["irs_lqr", "--iters", "3", "--T", "20", "--N", "500"],
+                                  ["irs_lqr", "--iters", "2", "--T", "12", "--N", "300", "--bounds", "rel", "--device-rng"],
+                                  ["cem", "--iters", "3", "--T", "12", "--N", "60"]])
+def test_planar_hand_example_runner(amd, argv, monkeypatch, capsys):
+    """examples/planar_hand/run_planar_hand{,_cem}.py twins run end to end and descend."""
+    import examples.run_planar_hand as run
+    monkeypatch.setattr("sys.argv", ["run_planar_hand.py", "--quiet"] + argv)
+    run.main()
+    out = capsys.readouterr().out
+    hist = [float(v) for v in out.split("cost history:")[1].split()]
+    assert len(hist) == int(argv[2]) + 2 and all(np.isfinite(hist)) and min(hist[1:]) < hist[0]
