@@ -115,20 +115,24 @@ struct PlanarHandModel {
                 }
             }
         }
-        // dual: W = J D^-1 J', r = phi - J D^-1 b
-        S W[NC][NC], r[NC], lam[NC], invW[NC];
+        // dual: W = J D^-1 J', r = phi - J D^-1 b   (JD = J D^-1 formed once)
+        S W[NC][NC], r[NC], lam[NC], invW[NC], JD[NC][NX], Db[NX];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) Db[k] = b[k] * Dinv[k];
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) JD[i][k] = J[i][k] * Dinv[k];
             S ri = phi[i];
 #pragma unroll
-            for (int k = 0; k < NX; ++k) ri = ri - J[i][k] * b[k] * Dinv[k];
+            for (int k = 0; k < NX; ++k) ri = ri - J[i][k] * Db[k];
             r[i] = ri;
             lam[i] = ri * T(0);
 #pragma unroll
             for (int j = 0; j <= i; ++j) {
-                S w = J[i][0] * J[j][0] * Dinv[0];
+                S w = JD[i][0] * J[j][0];
 #pragma unroll
-                for (int k = 1; k < NX; ++k) w = w + J[i][k] * J[j][k] * Dinv[k];
+                for (int k = 1; k < NX; ++k) w = w + JD[i][k] * J[j][k];
                 W[i][j] = w;
                 W[j][i] = w;
             }

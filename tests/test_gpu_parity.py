@@ -968,3 +968,39 @@ def test_planar_hand_example_runner(amd, argv, monkeypatch, capsys):
     out = capsys.readouterr().out
     hist = [float(v) for v in out.split("cost history:")[1].split()]
     assert len(hist) == int(argv[2]) + 2 and all(np.isfinite(hist)) and min(hist[1:]) < hist[0]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_quasistatic_active_set_random_problems(amd, seed):
+    """The active-set descent on randomised planar-hand problems (nominal trajectory, goal, bound
+    widths, cost weights): device == oracle twin, both kinds, including tails that need the primal
+    safeguard."""
+    from irs_mpc_amd import device as dev
+    rng = np.random.default_rng(100 + seed)
+    T = int(rng.integers(12, 30))
+    sys_d, sys_o, x0, _ = _hand_setup(amd, T)
+    idx = sys_o.indices_u_into_x
+    u_trj = np.tile(x0[3:], (T, 1)) + 0.03 * rng.normal(size=(T, 4)).cumsum(axis=0) / np.sqrt(T)
+    x_trj = orc.rollout(sys_o, x0, u_trj)
+    du = 0.1 * rng.normal(size=(T, 300, 4))
+    At, Bt, ct = orc.zero_order_B_decoupled(sys_o, x_trj, u_trj, du)
+    q = np.array([1e-3, 1e-3, 10, 1e-3, 1e-3, 1e-3, 1e-3]) * rng.uniform(0.3, 3.0, size=7)
+    Q, Qd, R = np.diag(q), np.diag(rng.uniform(10, 200) * q), np.diag(rng.uniform(0.5, 10, size=4))
+    xd = np.tile(x0 + np.concatenate([rng.uniform(-0.3, 0.3, 2), rng.uniform(-0.6, 0.6, 1), np.zeros(4)]), (T + 1, 1))
+    w = rng.uniform(0.01, 0.08)
+    dm = sys_d.dm()
+    for kind in ("abs", "rel"):
+        ub = np.array([-np.ones(4) * w, np.ones(4) * w]) if kind == "abs" else None
+        rb = np.array([-np.ones(4) * w, np.ones(4) * w]) if kind == "rel" else None
+        rows = orc.quasistatic_bounds(x_trj, idx, None, ub, rb)
+        lo, hi = (rows[2], rows[3]) if kind == "abs" else (rows[4], rows[5])
+        xa, ua, stats = orc.local_descent_quasistatic_as(sys_o, At, Bt, ct, Q, Qd, R, x0, xd, lo, hi, kind)
+        assert all(st[1] >= 0 for st in stats)
+        kw = dict(u_lo=dev.to_dev(lo), u_hi=dev.to_dev(hi)) if kind == "abs" else \
+            dict(du_lo=dev.to_dev(lo), du_hi=dev.to_dev(hi))
+        o = dm.quasistatic_box_descent(*[dev.to_dev(a) for a in (At, Bt, ct, Q, Qd, R, xd, x0)], solver=2,
+                                       max_iter=2000, eps=1e-10, **kw)
+        info = o["info"].cpu().numpy()
+        assert info[0] == 0 and info[2] == 0, (kind, info)
+        np.testing.assert_allclose(o["u_new"].cpu().numpy(), ua, rtol=0, atol=1e-8, err_msg=kind)
+        np.testing.assert_allclose(o["x_new"].cpu().numpy(), xa, rtol=0, atol=1e-8, err_msg=kind)
