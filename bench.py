@@ -57,11 +57,14 @@ class Workload:
             self.system = PlanarHandDynamics(0.1)
             self.mode, self.mode_name = _lib.SMOOTH_ZERO_ORDER_B, "ZERO_ORDER_B"
             # examples/planar_hand/run_planar_hand.py:31-44 (initial grasp), :113-131 (costs, goal)
-            self.x0 = np.array([0.0, 0.35, 0.0, -np.pi / 4, -np.pi / 4, np.pi / 4, np.pi / 4])
-            self.u_trj = np.tile(self.x0[3:], (self.T, 1))
-            q = np.array([1e-3, 1e-3, 10.0, 1e-3, 1e-3, 1e-3, 1e-3])
+            sd = self.system
+            parts = lambda obj, arm_l, arm_r: sd.get_x_from_q_dict({"sphere": obj, "arm_left": arm_l, "arm_right": arm_r})
+            self.idx = sd.get_u_indices_into_x()
+            self.x0 = parts([0.0, 0.35, 0.0], [-np.pi / 4, -np.pi / 4], [np.pi / 4, np.pi / 4])
+            self.u_trj = np.tile(self.x0[self.idx], (self.T, 1))
+            q = parts([1e-3, 1e-3, 10.0], [1e-3, 1e-3], [1e-3, 1e-3])
             self.Q, self.Qd, self.R = np.diag(q), np.diag(100 * q), 5.0 * np.eye(4)
-            self.xd = np.tile(self.x0 + np.array([0.3, -0.1, 0.5, 0, 0, 0, 0]), (self.T + 1, 1))
+            self.xd = np.tile(self.x0 + parts([0.3, -0.1, 0.5], [0, 0], [0, 0]), (self.T + 1, 1))
             self.std_x, self.std_u = 0.0, 0.3          # run_planar_hand.py:146
             self.label = "planar_hand quasi-dynamic contact, zero-order-B smoothing (the metric's config)"
             self.kernel = "smooth_kernel<PlanarHandModel, ZERO_ORDER_B>"
@@ -227,7 +230,7 @@ def main():
             # IrsLqrQuasistatic.local_descent (irs_lqr_quasistatic.py:286-345) as run_planar_hand.py
             # sets it up: du cost, trust region u_bounds_abs = +-0.5 h around the nominal actuated
             # positions (:138-139), T re-solved tail QPs, contact dynamics in the loop; one launch
-            nom = x_trj[:-1].index_select(1, torch.tensor([3, 4, 5, 6], device=x_trj.device))
+            nom = x_trj[:-1].index_select(1, torch.as_tensor(w.idx, device=x_trj.device))
             u_lo, u_hi = (nom - 0.5 * w.system.h).contiguous(), (nom + 0.5 * w.system.h).contiguous()
             qs_out = {}
 

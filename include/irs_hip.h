@@ -54,7 +54,8 @@ typedef enum irs_model_id {
                                  contact by branching); params = {h, d}                                */
     IRS_MODEL_PLANAR_HAND = 4 /* examples/planar_hand (QuasistaticDynamics over the external simulator,
                                  irs_lqr/quasistatic_dynamics.py:136-164): planar quasi-dynamic contact,
-                                 Anitescu convex step; q = [xo,yo,th, ql1,ql2, qr1,qr2], u = joint commands;
+                                 Anitescu convex step; x = [xo, ql1, qr1, yo, ql2, qr2, th] (the reference's order,
+                                 planar_hand_analysis.py:61-67), u = [ql1, ql2, qr1, qr2] joint commands;
                                  params = {h, g, mass, R, mu, kp1, kp2, l1, l2, r_link, base_x, pgs_iters};
                                  no Jacobian: FIRST_ORDER / exact are unsupported, ZERO_ORDER_B returns the
                                  decoupled (A,B) of irs_lqr_quasistatic.py:275-284.  PARITY UNPINNED.    */

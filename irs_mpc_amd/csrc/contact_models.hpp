@@ -29,8 +29,10 @@ template <typename S>
 IRS_HD S irs_max0(const S& a) { return irs_value(a) > 0 ? a : S(a * (typename scalar_of<S>::type)(0)); }
 
 // examples/planar_hand: a disc (radius R) cradled by two 2-link arms with capsule links.
-//   q = [xo, yo, th, ql1, ql2, qr1, qr2]   (object first, then left / right joint angles)
-//   u = commanded joint angles [ql1, ql2, qr1, qr2]      (indices_u_into_x = 3..6)
+//   x = [xo, ql1, qr1, yo, ql2, qr2, th]   -- the reference's state order (Drake's velocity indices
+//       of the plant; examples/planar_hand/analysis/planar_hand_analysis.py:61-67)
+//   u = commanded joint angles [ql1, ql2, qr1, qr2]      (indices_u_into_x = 1, 4, 2, 5)
+//   internally q = [xo, yo, th, ql1, ql2, qr1, qr2] (object first); PERM maps q's index to x's
 //   params = {h, g, mass, R, mu, kp1, kp2, l1, l2, r_link, base_x, pgs_iters}
 // Geometry (planar_hand_analysis.py:69-101): bases (-+base_x, 0); the left arm's first joint
 // angle is offset by pi; link lengths l1, l2; capsule radius r_link.
@@ -41,11 +43,17 @@ struct PlanarHandModel {
     // IrsLqrQuasistatic.decouple_AB_matrices (irs_lqr_quasistatic.py:275-284) -- every contact
     // example sets decouple_AB = True, which discards the sampled A anyway
     static constexpr bool HAS_JACOBIAN = false;
-    IRS_HD static int u_into_x(int j) { return 3 + j; }
+    IRS_HD static constexpr int perm(int k) {       // internal index k -> index in the reference's x
+        return k == 0 ? 0 : k == 1 ? 3 : k == 2 ? 6 : k == 3 ? 1 : k == 4 ? 4 : k == 5 ? 2 : 5;
+    }
+    IRS_HD static int u_into_x(int j) { return perm(3 + j); }
 
     template <typename S>
-    IRS_HD static void step(const ModelParams& p, const S* q, const S* u, S* qn) {
+    IRS_HD static void step(const ModelParams& p, const S* x_ext, const S* u, S* xn_ext) {
         using T = typename scalar_of<S>::type;
+        S q[NX], qn[NX];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) q[k] = x_ext[perm(k)];
         const T h = T(p.v[0]), g = T(p.v[1]), mass = T(p.v[2]), R = T(p.v[3]), mu = T(p.v[4]);
         const T kp1 = T(p.v[5]), kp2 = T(p.v[6]), l1 = T(p.v[7]), l2 = T(p.v[8]), rl = T(p.v[9]), bx = T(p.v[10]);
         const int iters = (int)p.v[11];
@@ -186,5 +194,7 @@ struct PlanarHandModel {
             for (int i = 0; i < NC; ++i) f = f + J[i][k] * lam[i];
             qn[k] = q[k] + f * Dinv[k];
         }
+#pragma unroll
+        for (int k = 0; k < NX; ++k) xn_ext[perm(k)] = qn[k];
     }
 };

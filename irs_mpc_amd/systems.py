@@ -70,7 +70,8 @@ class ThreeCartDynamics(DynamicalSystem):
 class PlanarHandDynamics(DynamicalSystem):
     """Device twin of `QuasistaticDynamics` (irs_lqr/quasistatic_dynamics.py:15-164) for the
     planar hand of examples/planar_hand (planar_hand_setup.py:8-27): a disc cradled by two
-    2-link arms, q = [xo, yo, th, ql1, ql2, qr1, qr2], u = commanded joint angles.  Steps the
+    2-link arms, x = [xo, ql1, qr1, yo, ql2, qr2, th] (the reference's order), u = commanded joint
+    angles [ql1, ql2, qr1, qr2].  Steps the
     Anitescu convex quasi-dynamic QP on the device (csrc/contact_models.hpp); the reference steps
     the external quasistatic_simulator, so parity for this model is UNPINNED.  No Jacobian:
     `jacobian_xu*` raise, `ZERO_ORDER_B` smoothing returns the decoupled (A,B)."""
@@ -96,8 +97,9 @@ class PlanarHandDynamics(DynamicalSystem):
         self.models_unactuated = ["sphere"]
         self.models_actuated = ["arm_left", "arm_right"]
         self.models_all = self.models_unactuated + self.models_actuated
-        self.position_indices = {"sphere": np.array([0, 1, 2]), "arm_left": np.array([3, 4]),
-                                 "arm_right": np.array([5, 6])}
+        # the reference's state order (planar_hand_analysis.py:61-67): x = [xo, ql1, qr1, yo, ql2, qr2, th]
+        self.position_indices = {"sphere": np.array([0, 3, 6]), "arm_left": np.array([1, 4]),
+                                 "arm_right": np.array([2, 5])}
         self.velocity_indices = self.position_indices
 
     # ---- quasistatic_dynamics.py:57-130: vector <-> per-model dict helpers --------------

@@ -291,7 +291,10 @@ class PlanarHandOracle:
         min_dq 1/2 dq' D dq + b' dq   s.t.  phi_i + J_i dq >= 0,    q+ = q + dq
         D = diag(M_u / h^2, K_a),  b = (-tau_u, K_a (q_a - u))
 
-    q = [xo, yo, th, ql1, ql2, qr1, qr2], u = commanded joint angles.  `dynamics` solves the dual
+    State in the REFERENCE's order (Drake's velocity indices of the plant; read off
+    examples/planar_hand/analysis/planar_hand_analysis.py:61-67): x = [xo, ql1, qr1, yo, ql2, qr2, th];
+    u = commanded joint angles [ql1, ql2, qr1, qr2], so indices_u_into_x = [1, 4, 2, 5].  Internally
+    q = x[PERM] = [xo, yo, th, ql1, ql2, qr1, qr2].  `dynamics` solves the dual
     by `pgs_iters` projected Gauss-Seidel sweeps (what the device functor does, same order);
     `dynamics_exact` solves the same QP to optimality (active-set via NNLS) as the physics check.
     """
@@ -308,15 +311,24 @@ class PlanarHandOracle:
         self.r_link = 0.05
         self.base_x = 0.1
         self.pgs_iters = pgs_iters
-        self.indices_u_into_x = np.array([3, 4, 5, 6])
+        self.indices_u_into_x = self.PERM[3:].copy()
+
+    PERM = np.array([0, 3, 6, 1, 4, 2, 5])       # internal q index -> index in the reference's x
+
+    @classmethod
+    def pack(cls, obj, left, right):
+        """x in the reference's order from the object pose (xo, yo, th) and the joint angles."""
+        x = np.zeros(7)
+        x[cls.PERM] = np.concatenate([obj, left, right])
+        return x
 
     def params(self):
         return [self.h, self.g, self.mass, self.R, self.mu, self.kp[0], self.kp[1], self.l1, self.l2,
                 self.r_link, self.base_x, self.pgs_iters]
 
     def _qp(self, q, u):
-        """Batched QP data: Dinv (7,), b (B,7), J (B,8,7), phi (B,8)."""
-        q = np.atleast_2d(q)
+        """Batched QP data in the INTERNAL order: Dinv (7,), b (B,7), J (B,8,7), phi (B,8)."""
+        q = np.atleast_2d(q)[:, self.PERM]
         u = np.atleast_2d(u)
         B = q.shape[0]
         h, m, R, mu = self.h, self.mass, self.R, self.mu
@@ -376,7 +388,9 @@ class PlanarHandOracle:
                 new = np.maximum(lam[:, i] - g[:, i] * invW[:, i], 0.0)
                 g += W[:, :, i] * (new - lam[:, i])[:, None]
                 lam[:, i] = new
-        return np.atleast_2d(x) + (np.einsum("bik,bi->bk", J, lam) - b) * Dinv
+        out = np.array(np.atleast_2d(x), dtype=float)
+        out[:, self.PERM] += (np.einsum("bik,bi->bk", J, lam) - b) * Dinv
+        return out
 
     def dynamics(self, x, u):
         return self.dynamics_batch(x[None], u[None])[0]
@@ -392,7 +406,9 @@ class PlanarHandOracle:
         res = minimize(lambda l: 0.5 * l.dot(W).dot(l) + r.dot(l), np.zeros(8), jac=lambda l: W.dot(l) + r,
                        bounds=[(0, None)] * 8, method="L-BFGS-B", options={"ftol": 1e-15, "gtol": 1e-12,
                                                                              "maxiter": 10000})
-        return x + (J.T.dot(res.x) - b) * Dinv
+        out = np.array(x, dtype=float)
+        out[self.PERM] += (J.T.dot(res.x) - b) * Dinv
+        return out
 
     def jacobian_xu(self, x, u):
         raise NotImplementedError("no differentiable step; see zero_order_B_decoupled")

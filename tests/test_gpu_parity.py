@@ -707,12 +707,18 @@ def test_example_runner(amd, argv, monkeypatch, capsys):
 
 
 # ---------------------------------------------------------------- planar quasi-dynamic contact (a7, unpinned)
+HAND = orc.PlanarHandOracle
+HAND_IDX = np.array([1, 4, 2, 5])        # indices_u_into_x in the reference's state order
+HAND_Q = HAND.pack([1e-3, 1e-3, 10.0], [1e-3, 1e-3], [1e-3, 1e-3])          # run_planar_hand.py:113-121
+HAND_GOAL = HAND.pack([0.3, -0.1, 0.5], [0, 0], [0, 0])                     # :123-125
+
+
 def _hand_setup(amd, T, settle=4):
     sys_d, sys_o = amd.PlanarHandDynamics(0.1), orc.PlanarHandOracle(0.1)
-    x0 = np.array([0.0, 0.35, 0.0, -np.pi / 4, -np.pi / 4, np.pi / 4, np.pi / 4])   # run_planar_hand.py:31-44
+    x0 = HAND.pack([0.0, 0.35, 0.0], [-np.pi / 4, -np.pi / 4], [np.pi / 4, np.pi / 4])   # run_planar_hand.py:31-44
     for _ in range(settle):
-        x0 = sys_o.dynamics(x0, x0[3:] * 0 + np.array([-np.pi / 4, -np.pi / 4, np.pi / 4, np.pi / 4]))
-    u_trj = np.tile(x0[3:], (T, 1)) + 0.02 * np.sin(np.arange(T))[:, None] * np.array([1, -1, -1, 1])
+        x0 = sys_o.dynamics(x0, np.array([-np.pi / 4, -np.pi / 4, np.pi / 4, np.pi / 4]))
+    u_trj = np.tile(x0[HAND_IDX], (T, 1)) + 0.02 * np.sin(np.arange(T))[:, None] * np.array([1, -1, -1, 1])
     return sys_d, sys_o, x0, u_trj
 
 
@@ -721,7 +727,7 @@ def test_planar_hand_dynamics_vs_oracle(amd):
     sys_d, sys_o, x0, _ = _hand_setup(amd, 1)
     rng = np.random.default_rng(11)
     X = x0 + 0.03 * rng.normal(size=(512, 7))
-    U = x0[3:] + 0.1 * rng.normal(size=(512, 4))
+    U = x0[HAND_IDX] + 0.1 * rng.normal(size=(512, 4))
     got = sys_d.dynamics_batch(X, U)
     np.testing.assert_allclose(got, sys_o.dynamics_batch(X, U), rtol=0, atol=1e-10)
     np.testing.assert_allclose(sys_d.dynamics(X[0], U[0]), sys_o.dynamics(X[0], U[0]), rtol=0, atol=1e-10)
@@ -750,7 +756,7 @@ def test_planar_hand_zero_order_B_decoupled_vs_oracle(amd):
     np.testing.assert_allclose(Bt.cpu().numpy(), Bo, rtol=0, atol=2e-4)
     np.testing.assert_allclose(ct.cpu().numpy(), co, rtol=0, atol=2e-4)
     # the object rows of B see the contacts: pushing the fingers in moves the disc
-    assert np.abs(Bo[:, :3, :]).max() > 0.05
+    assert np.abs(Bo[:, HAND.PERM[:3], :]).max() > 0.05
     # first-order smoothing is refused for a model without a Jacobian
     with pytest.raises(Exception):
         dm.smooth(1, xd, ud, dev.to_dev(np.zeros((T, N, 7), np.float32), dev.F32), dev.to_dev(du, dev.F32))
@@ -768,9 +774,9 @@ def test_planar_hand_descent_runs(amd):
     dm = sys_d.dm()
     o = dm.smooth(SMOOTH_ZERO_ORDER_B, dev.to_dev(x_trj), dev.to_dev(u_trj), None, dev.to_dev(du, dev.F32))
     At, Bt, ct = o["At"], o["Bt"], o["ct"]
-    Q = np.diag([1e-3, 1e-3, 10, 1e-3, 1e-3, 1e-3, 1e-3])          # run_planar_hand.py:113-121
+    Q = np.diag(HAND_Q)
     R = 5.0 * np.eye(4)
-    xd = np.tile(x0 + np.array([0.0, 0.0, 0.3, 0, 0, 0, 0]), (T + 1, 1))
+    xd = np.tile(x0 + HAND.pack([0.0, 0.0, 0.3], [0, 0], [0, 0]), (T + 1, 1))
     out = dm.tvlqr_descent(At, Bt, ct, dev.to_dev(Q), dev.to_dev(100 * Q), dev.to_dev(R), dev.to_dev(xd),
                            dev.to_dev(x0))
     K, k, x_new, cost = out["K"], out["k"], out["x_new"], out["cost"]
@@ -785,13 +791,12 @@ def test_planar_hand_descent_runs(amd):
 
 def _hand_problem(amd, T, N, seed):
     sys_d, sys_o, x0, _ = _hand_setup(amd, T)
-    u_trj = np.tile(x0[3:], (T, 1))
+    u_trj = np.tile(x0[HAND_IDX], (T, 1))
     x_trj = orc.rollout(sys_o, x0, u_trj)
     du = (np.random.default_rng(seed).normal(size=(T, N, 4)) * 0.1).astype(np.float32)
     At, Bt, ct = orc.zero_order_B_decoupled(sys_o, x_trj, u_trj, du.astype(np.float64))
-    q = np.array([1e-3, 1e-3, 10, 1e-3, 1e-3, 1e-3, 1e-3])          # run_planar_hand.py:113-131
-    Q, Qd, R = np.diag(q), np.diag(100 * q), 5.0 * np.eye(4)
-    xd = np.tile(x0 + np.array([0.3, -0.1, 0.5, 0, 0, 0, 0]), (T + 1, 1))
+    Q, Qd, R = np.diag(HAND_Q), np.diag(100 * HAND_Q), 5.0 * np.eye(4)
+    xd = np.tile(x0 + HAND_GOAL, (T + 1, 1))
     return sys_d, sys_o, x0, u_trj, x_trj, du, (At, Bt, ct), (Q, Qd, R, xd)
 
 
@@ -917,7 +922,7 @@ def test_quasistatic_active_set_full_horizon(amd, kind):
         x = x0.copy()
         for t in range(T):
             z = np.concatenate([x, x[idx]])
-            u = z[7:] + K[t] @ z + k[t]
+            u = z[7:] + K[t] @ z + k[t]          # z = [x; u_prev]
             np.testing.assert_allclose(ua[t], u, rtol=0, atol=1e-9)
             x = sys_o.dynamics(x, u)
 
@@ -980,13 +985,14 @@ def test_quasistatic_active_set_random_problems(amd, seed):
     T = int(rng.integers(12, 30))
     sys_d, sys_o, x0, _ = _hand_setup(amd, T)
     idx = sys_o.indices_u_into_x
-    u_trj = np.tile(x0[3:], (T, 1)) + 0.03 * rng.normal(size=(T, 4)).cumsum(axis=0) / np.sqrt(T)
+    u_trj = np.tile(x0[HAND_IDX], (T, 1)) + 0.03 * rng.normal(size=(T, 4)).cumsum(axis=0) / np.sqrt(T)
     x_trj = orc.rollout(sys_o, x0, u_trj)
     du = 0.1 * rng.normal(size=(T, 300, 4))
     At, Bt, ct = orc.zero_order_B_decoupled(sys_o, x_trj, u_trj, du)
-    q = np.array([1e-3, 1e-3, 10, 1e-3, 1e-3, 1e-3, 1e-3]) * rng.uniform(0.3, 3.0, size=7)
+    q = HAND_Q * rng.uniform(0.3, 3.0, size=7)
     Q, Qd, R = np.diag(q), np.diag(rng.uniform(10, 200) * q), np.diag(rng.uniform(0.5, 10, size=4))
-    xd = np.tile(x0 + np.concatenate([rng.uniform(-0.3, 0.3, 2), rng.uniform(-0.6, 0.6, 1), np.zeros(4)]), (T + 1, 1))
+    xd = np.tile(x0 + HAND.pack(np.concatenate([rng.uniform(-0.3, 0.3, 2), rng.uniform(-0.6, 0.6, 1)]), [0, 0], [0, 0]),
+                 (T + 1, 1))
     w = rng.uniform(0.01, 0.08)
     dm = sys_d.dm()
     for kind in ("abs", "rel"):

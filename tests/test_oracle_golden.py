@@ -309,26 +309,26 @@ def test_device_gaussian_moments():
 # ---------------------------------------------------------------- planar quasi-dynamic contact (unpinned)
 def _hand_x0():
     # examples/planar_hand/run_planar_hand.py:31-44
-    return np.array([0.0, 0.35, 0.0, -np.pi / 4, -np.pi / 4, np.pi / 4, np.pi / 4])
+    return orc.PlanarHandOracle.pack([0.0, 0.35, 0.0], [-np.pi / 4, -np.pi / 4], [np.pi / 4, np.pi / 4])
 
 
 def test_planar_hand_free_fall_and_servo():
     """No contact: the disc moves by -g h^2 (quasi-dynamic, zero initial velocity) and the joints
     reach their commands exactly (stiffness-only actuated rows)."""
     o = orc.PlanarHandOracle(0.1)
-    x = _hand_x0()
-    x[1] = 2.0                                  # far above the hand
-    u = x[3:] + np.array([0.05, -0.02, 0.03, 0.01])
+    x = orc.PlanarHandOracle.pack([0.0, 2.0, 0.0], [-np.pi / 4, -np.pi / 4], [np.pi / 4, np.pi / 4])   # far above
+    idx, obj = o.indices_u_into_x, o.PERM[:3]
+    u = x[idx] + np.array([0.05, -0.02, 0.03, 0.01])
     xn = o.dynamics(x, u)
-    np.testing.assert_allclose(xn[:3], [0.0, 2.0 - 10.0 * 0.1 ** 2, 0.0], atol=1e-14)
-    np.testing.assert_allclose(xn[3:], u, atol=1e-14)
+    np.testing.assert_allclose(xn[obj], [0.0, 2.0 - 10.0 * 0.1 ** 2, 0.0], atol=1e-14)
+    np.testing.assert_allclose(xn[idx], u, atol=1e-14)
 
 
 def test_planar_hand_pgs_converges_to_exact_qp_and_stays_feasible():
     rng = np.random.default_rng(3)
     o = orc.PlanarHandOracle(0.1, pgs_iters=2000)
     x = _hand_x0()
-    u = x[3:].copy()
+    u = x[o.indices_u_into_x].copy()
     for _ in range(5):
         x = o.dynamics(x, u)                    # settle into the cradle
     for _ in range(10):
@@ -338,17 +338,18 @@ def test_planar_hand_pgs_converges_to_exact_qp_and_stays_feasible():
         np.testing.assert_allclose(xn, o.dynamics_exact(xs, us), atol=5e-7)
         # linearised non-penetration holds at the optimum
         Dinv, b, J, phi = o._qp(xs, us)
-        assert np.all(phi[0] + J[0].dot(xn - xs) > -1e-8)
+        assert np.all(phi[0] + J[0].dot((xn - xs)[o.PERM]) > -1e-8)      # J is in the internal order
 
 
 def test_planar_hand_symmetric_grasp_stays_symmetric():
     o = orc.PlanarHandOracle(0.1, pgs_iters=2000)
     x = _hand_x0()
     for _ in range(3):
-        x = o.dynamics(x, _hand_x0()[3:])
-    assert abs(x[0]) < 1e-9 and abs(x[2]) < 1e-9
-    np.testing.assert_allclose(x[3:5], -x[5:7], atol=1e-9)
-    assert 0.30 < x[1] < 0.35                   # resting in the cradle, not through it
+        x = o.dynamics(x, _hand_x0()[o.indices_u_into_x])
+    xo, yo, th, l1, l2, r1, r2 = x[o.PERM]
+    assert abs(xo) < 1e-9 and abs(th) < 1e-9
+    np.testing.assert_allclose([l1, l2], [-r1, -r2], atol=1e-9)
+    assert 0.30 < yo < 0.35                     # resting in the cradle, not through it
 
 
 def test_quasistatic_tail_qp_kkt_certificate():
@@ -359,14 +360,14 @@ def test_quasistatic_tail_qp_kkt_certificate():
     o = orc.PlanarHandOracle(0.1)
     x0 = _hand_x0()
     for _ in range(4):
-        x0 = o.dynamics(x0, _hand_x0()[3:])
-    u_trj = np.tile(x0[3:], (T, 1))
+        x0 = o.dynamics(x0, _hand_x0()[o.indices_u_into_x])
+    u_trj = np.tile(x0[o.indices_u_into_x], (T, 1))
     x_trj = orc.rollout(o, x0, u_trj)
     du = 0.1 * np.random.default_rng(5).normal(size=(T, N, 4))
     At, Bt, ct = orc.zero_order_B_decoupled(o, x_trj, u_trj, du)
-    q = np.array([1e-3, 1e-3, 10, 1e-3, 1e-3, 1e-3, 1e-3])
+    q = orc.PlanarHandOracle.pack([1e-3, 1e-3, 10], [1e-3, 1e-3], [1e-3, 1e-3])
     Q, Qd, R = np.diag(q), np.diag(100 * q), 5 * np.eye(4)
-    xd = np.tile(x0 + np.array([0.3, -0.1, 0.5, 0, 0, 0, 0]), (T + 1, 1))
+    xd = np.tile(x0 + orc.PlanarHandOracle.pack([0.3, -0.1, 0.5], [0, 0], [0, 0]), (T + 1, 1))
     idx, m = o.indices_u_into_x, 4
     rows = orc.quasistatic_bounds(x_trj, idx, None, np.array([-np.ones(4) * 0.05, np.ones(4) * 0.05]),
                                   np.array([-np.ones(4) * 0.03, np.ones(4) * 0.03]))

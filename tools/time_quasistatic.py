@@ -14,18 +14,20 @@ T = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
 sysd = PlanarHandDynamics(0.1)
 dm = sysd.dm()
-x0 = np.array([0.0, 0.35, 0.0, -np.pi / 4, -np.pi / 4, np.pi / 4, np.pi / 4])
-u_trj = dev.to_dev(np.tile(x0[3:], (T, 1)))
-q = np.array([1e-3, 1e-3, 10.0, 1e-3, 1e-3, 1e-3, 1e-3])
+parts = lambda obj, arm_l, arm_r: sysd.get_x_from_q_dict({"sphere": obj, "arm_left": arm_l, "arm_right": arm_r})
+uidx = sysd.get_u_indices_into_x()
+x0 = parts([0.0, 0.35, 0.0], [-np.pi / 4, -np.pi / 4], [np.pi / 4, np.pi / 4])
+u_trj = dev.to_dev(np.tile(x0[uidx], (T, 1)))
+q = parts([1e-3, 1e-3, 10.0], [1e-3, 1e-3], [1e-3, 1e-3])
 Q, Qd, R = dev.to_dev(np.diag(q)), dev.to_dev(np.diag(100 * q)), dev.to_dev(5.0 * np.eye(4))
-xd = dev.to_dev(np.tile(x0 + np.array([0.3, -0.1, 0.5, 0, 0, 0, 0]), (T + 1, 1)))
+xd = dev.to_dev(np.tile(x0 + parts([0.3, -0.1, 0.5], [0, 0], [0, 0]), (T + 1, 1)))
 x0d = dev.to_dev(x0)
 x_trj, _ = dm.rollout_cost(x0d, u_trj, Q, R, xd)
 g = torch.Generator(device="cuda").manual_seed(0)
 du = 0.3 * torch.randn((T, N, 4), generator=g, device="cuda", dtype=torch.float32)
 o = dm.smooth(_lib.SMOOTH_ZERO_ORDER_B, x_trj, u_trj, None, du)
 At, Bt, ct = o["At"], o["Bt"], o["ct"]
-idx = torch.tensor([3, 4, 5, 6], device="cuda")
+idx = torch.as_tensor(uidx, device="cuda")
 nom = x_trj[:-1].index_select(1, idx).contiguous()
 cases = {"abs": dict(u_lo=(nom - 0.05).contiguous(), u_hi=(nom + 0.05).contiguous()),
          "rel": dict(du_lo=torch.full((T, 4), -0.03, dtype=torch.float64, device="cuda"),

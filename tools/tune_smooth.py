@@ -28,8 +28,8 @@ std = 1.0 if model == "pendulum" else 0.1
 u_trj = dev.to_dev(np.full((T, m), u0))
 x0 = np.zeros(n)
 if model == "planar_hand":      # examples/planar_hand/run_planar_hand.py:31-44
-    x0 = np.array([0.0, 0.35, 0.0, -np.pi / 4, -np.pi / 4, np.pi / 4, np.pi / 4])
-    u_trj = dev.to_dev(np.tile(x0[3:], (T, 1)))
+    x0 = sysd.get_x_from_q_dict({"sphere": [0.0, 0.35, 0.0], "arm_left": [-np.pi / 4] * 2, "arm_right": [np.pi / 4] * 2})
+    u_trj = dev.to_dev(np.tile(x0[sysd.get_u_indices_into_x()], (T, 1)))
 Q, R = dev.to_dev(np.eye(n)), dev.to_dev(np.eye(m))
 xd = dev.to_dev(np.zeros((T + 1, n)))
 x_trj, _ = dm.rollout_cost(dev.to_dev(x0), u_trj, Q, R, xd)
