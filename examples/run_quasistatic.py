@@ -1,15 +1,19 @@
 #!/usr/bin/env python3
-"""The reference's planar-hand scripts on the GPU:
+"""The reference's quasistatic contact scripts on the GPU:
 
-    python examples/run_planar_hand.py irs_lqr              # examples/planar_hand/run_planar_hand.py
-    python examples/run_planar_hand.py irs_lqr --bounds rel # u_bounds_rel instead of the trust region
-    python examples/run_planar_hand.py cem                  # examples/planar_hand/run_planar_hand_cem.py
+    python examples/run_quasistatic.py planar_hand irs_lqr       # examples/planar_hand/run_planar_hand.py
+    python examples/run_quasistatic.py planar_hand irs_lqr --bounds rel
+    python examples/run_quasistatic.py planar_hand cem           # .../run_planar_hand_cem.py
+    python examples/run_quasistatic.py box_pivoting irs_lqr      # examples/box_pivoting/run_box_pivoting.py
+    python examples/run_quasistatic.py box_pivoting cem          # .../run_box_pivoting_cem.py
 
-Problem data as in run_planar_hand.py:20-153 (horizon 3 s at h = 0.1, initial grasp, goal
-q_u0 + (0.3, -0.1, 0.5), Q/Qd/R dicts, u_bounds_abs = +-0.5 h, std_u_initial = 0.3 / iter^0.8,
-20 iterations) with two differences forced by the missing simulator: the contact step is the device
-functor (parity unpinned) and gradient_mode is "zero_order_B" (the script's
-"first_order" needs the simulator's derivatives); --N defaults to 1000 samples instead of 50.
+planar_hand: problem data as in run_planar_hand.py:20-153 (h = 0.1, initial grasp, goal
+q_u0 + (0.3, -0.1, 0.5), Q/Qd/R dicts, u_bounds_abs = +-0.5 h, std_u_initial = 0.3 / iter^0.8).
+box_pivoting: run_box_pivoting.py:20-131 (hand sweeps from (-0.5, 0.5) to (0.5, 0.5), goal box pose
+q_u0 + (1, 0.5, -pi/2), Q = (5, 5, 50 | 0, 0), R = 1e3, u_bounds_rel = +-0.15 h, std 0.1^(0.5 iter)).
+Two differences forced by the missing simulator: the contact step is the device functor (DESIGN.md 3,
+parity unpinned) and gradient_mode is "zero_order_B" (planar_hand's "first_order" needs the
+simulator's derivatives); --N defaults to 1000 samples instead of 50 / 100.
 """
 import argparse
 import os
@@ -20,6 +24,21 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import irs_mpc_amd as amd  # noqa: E402
+
+
+def box_problem(T, h=0.1):
+    q_dynamics = amd.BoxPivotingDynamics(h)
+    idx_u, idx_a = "box", "hand"
+    q_u0 = np.array([0.0, 0.5, 0.0])
+    qa0, qa1 = np.array([-0.5, 0.5]), np.array([0.5, 0.5])
+    x0 = q_dynamics.get_x_from_q_dict({idx_u: q_u0, idx_a: qa0})
+    # FirstOrderHold from qa0 to qa1, sampled at t + h (run_box_pivoting.py:24-26, :83-87)
+    u_traj_0 = np.stack([qa0 + (qa1 - qa0) * (t + 1) / T for t in range(T)])
+    Q_dict = {idx_u: np.array([5, 5, 50]), idx_a: np.array([0.0, 0.0])}
+    Qd_dict = {model: Q_i * 1 for model, Q_i in Q_dict.items()}
+    R_dict = {idx_a: 1e3 * np.array([1, 1])}
+    xd = q_dynamics.get_x_from_q_dict({idx_u: q_u0 + np.array([1.0, 0.5, -np.pi / 2]), idx_a: qa0})
+    return q_dynamics, x0, u_traj_0, Q_dict, Qd_dict, R_dict, np.tile(xd, (T + 1, 1))
 
 
 def problem(T, h=0.1):
@@ -38,11 +57,13 @@ def problem(T, h=0.1):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("system", choices=["planar_hand", "box_pivoting"])
     ap.add_argument("method", choices=["irs_lqr", "cem"])
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--T", type=int, default=30)
     ap.add_argument("--N", type=int, default=1000, help="samples per timestep / CEM batch size")
-    ap.add_argument("--bounds", choices=["abs", "rel", "none"], default="abs")
+    ap.add_argument("--bounds", choices=["abs", "rel", "none"], default=None,
+                    help="default: the script's own (planar_hand: abs, box_pivoting: rel)")
     ap.add_argument("--device-rng", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--csv", default=None)
@@ -50,7 +71,10 @@ def main():
     a = ap.parse_args()
 
     h = 0.1
-    q_dynamics, x0, u_traj_0, Q_dict, Qd_dict, R_dict, x_trj_d = problem(a.T, h)
+    hand = a.system == "planar_hand"
+    q_dynamics, x0, u_traj_0, Q_dict, Qd_dict, R_dict, x_trj_d = (problem if hand else box_problem)(a.T, h)
+    if a.bounds is None:
+        a.bounds = "abs" if hand else "rel"
     np.random.seed(a.seed)
     if a.method == "irs_lqr":
         params = amd.IrsLqrQuasistaticParameters()
@@ -59,10 +83,15 @@ def main():
         dim_u = q_dynamics.dim_u
         if a.bounds == "abs":       # run_planar_hand.py:138-139
             params.u_bounds_abs = np.array([-np.ones(dim_u) * 0.5 * h, np.ones(dim_u) * 0.5 * h])
-        elif a.bounds == "rel":     # e.g. examples/box_pushing/run_box_pushing.py:117
-            params.u_bounds_rel = np.array([-np.ones(dim_u) * 0.3 * h, np.ones(dim_u) * 0.3 * h])
-        params.sampling = lambda u_initial, it: u_initial / (it ** 0.8)     # :142-143
-        params.std_u_initial = np.ones(dim_u) * 0.3
+        elif a.bounds == "rel":     # run_box_pivoting.py:119-120 (0.15 h); run_box_pushing.py:117
+            w = 0.3 * h if hand else 0.15 * h
+            params.u_bounds_rel = np.array([-np.ones(dim_u) * w, np.ones(dim_u) * w])
+        if hand:
+            params.sampling = lambda u_initial, it: u_initial / (it ** 0.8)     # run_planar_hand.py:142-146
+            params.std_u_initial = np.ones(dim_u) * 0.3
+        else:
+            params.sampling = lambda u_initial, it: u_initial ** (0.5 * it)     # run_box_pivoting.py:122-126
+            params.std_u_initial = np.ones(dim_u) * 0.1
         params.num_samples = a.N
         params.publish_every_iteration = False
         if a.device_rng:

@@ -52,13 +52,17 @@ typedef enum irs_model_id {
     IRS_MODEL_BICYCLE = 2,    /* examples/bicycle/bicycle_dynamics.py:8-132; params = {h}              */
     IRS_MODEL_THREE_CART = 3, /* examples/three_cart/three_cart_dynamics.py:8-107 (scalar `dynamics`:
                                  contact by branching); params = {h, d}                                */
-    IRS_MODEL_PLANAR_HAND = 4 /* examples/planar_hand (QuasistaticDynamics over the external simulator,
+    IRS_MODEL_PLANAR_HAND = 4, /* examples/planar_hand (QuasistaticDynamics over the external simulator,
                                  irs_lqr/quasistatic_dynamics.py:136-164): planar quasi-dynamic contact,
                                  Anitescu convex step; x = [xo, ql1, qr1, yo, ql2, qr2, th] (the reference's order,
                                  planar_hand_analysis.py:61-67), u = [ql1, ql2, qr1, qr2] joint commands;
                                  params = {h, g, mass, R, mu, kp1, kp2, l1, l2, r_link, base_x, pgs_iters};
                                  no Jacobian: FIRST_ORDER / exact are unsupported, ZERO_ORDER_B returns the
                                  decoupled (A,B) of irs_lqr_quasistatic.py:275-284.  PARITY UNPINNED.    */
+    IRS_MODEL_BOX_PIVOT = 5   /* examples/box_pivoting: a 1 m square box on the ground pivoted by a position-
+                                 controlled disc; x = [x_h, x_b, y_h, y_b, th_b] (box_pivoting_analysis.py:53-64),
+                                 u = commanded hand position; params = {h, g, mass, half, mu, kp, r_hand,
+                                 pgs_iters}; same contact scheme and restrictions as the planar hand.       */
 } irs_model_id;
 
 /* Smoothing estimators.                                                         */

@@ -28,6 +28,86 @@
 template <typename S>
 IRS_HD S irs_max0(const S& a) { return irs_value(a) > 0 ? a : S(a * (typename scalar_of<S>::type)(0)); }
 
+
+// Shared tail of every quasi-dynamic contact step:  min_dq 1/2 dq'D dq + b'dq  s.t.  phi + J dq >= 0
+// (D diagonal), solved through its dual  min_{lam >= 0} 1/2 lam'W lam + r'lam,  W = J D^-1 J',
+// r = phi - J D^-1 b, by `iters` projected Gauss-Seidel sweeps; qn = q + D^-1 (J'lam - b).
+// PGS runs in residual form: g = r + W lam is kept up to date, so one update is
+//   lam_i <- max(lam_i - g_i / W_ii, 0),  g += W[:,i] (lam_i_new - lam_i_old)
+// -- a 4-deep dependent chain and NC independent FMAs (NC/2 packed ones in f32) instead of an
+// NC-term dot product per update.  Fixed sweep count: deterministic, branch-free per sample.
+template <typename S, int NX, int NC>
+IRS_HD void irs_contact_qp_step(const S* q, const typename scalar_of<S>::type* Dinv, const S* b,
+                                const S (*J)[NX], const S* phi, int iters, S* qn) {
+    using T = typename scalar_of<S>::type;
+    static_assert(NC % 2 == 0, "friction generators come in pairs");
+    S W[NC][NC], r[NC], lam[NC], invW[NC], JD[NC][NX], Db[NX];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) Db[k] = b[k] * Dinv[k];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+#pragma unroll
+        for (int k = 0; k < NX; ++k) JD[i][k] = J[i][k] * Dinv[k];
+        S ri = phi[i];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) ri = ri - J[i][k] * Db[k];
+        r[i] = ri;
+        lam[i] = ri * T(0);
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            S w = JD[i][0] * J[j][0];
+#pragma unroll
+            for (int k = 1; k < NX; ++k) w = w + JD[i][k] * J[j][k];
+            W[i][j] = w;
+            W[j][i] = w;
+        }
+        invW[i] = S(T(1)) / W[i][i];
+    }
+    if constexpr (std::is_same<S, float>::value) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 Wc[NC][NC / 2], g2[NC / 2];
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+#pragma unroll
+            for (int k = 0; k < NC / 2; ++k) Wc[i][k] = f2{W[2 * k][i], W[2 * k + 1][i]};
+#pragma unroll
+        for (int k = 0; k < NC / 2; ++k) g2[k] = f2{r[2 * k], r[2 * k + 1]};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                const float gi = (i & 1) ? g2[i / 2].y : g2[i / 2].x;
+                const float nw = fmaxf(fmaf(-gi, invW[i], lam[i]), 0.f);
+                const float dl = nw - lam[i];
+                lam[i] = nw;
+                const f2 d2 = f2{dl, dl};
+#pragma unroll
+                for (int k = 0; k < NC / 2; ++k) g2[k] = Wc[i][k] * d2 + g2[k];
+            }
+        }
+    } else {
+        S g[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) g[i] = r[i];
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                const S nw = irs_max0(S(lam[i] - g[i] * invW[i]));
+                const S dl = nw - lam[i];
+                lam[i] = nw;
+#pragma unroll
+                for (int j = 0; j < NC; ++j) g[j] = g[j] + W[j][i] * dl;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+        S f = -b[k];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) f = f + J[i][k] * lam[i];
+        qn[k] = q[k] + f * Dinv[k];
+    }
+}
+
 // examples/planar_hand: a disc (radius R) cradled by two 2-link arms with capsule links.
 //   x = [xo, ql1, qr1, yo, ql2, qr2, th]   -- the reference's state order (Drake's velocity indices
 //       of the plant; examples/planar_hand/analysis/planar_hand_analysis.py:61-67)
@@ -123,77 +203,119 @@ struct PlanarHandModel {
                 }
             }
         }
-        // dual: W = J D^-1 J', r = phi - J D^-1 b   (JD = J D^-1 formed once)
-        S W[NC][NC], r[NC], lam[NC], invW[NC], JD[NC][NX], Db[NX];
+        irs_contact_qp_step<S, NX, NC>(q, Dinv, b, J, phi, iters, qn);
 #pragma unroll
-        for (int k = 0; k < NX; ++k) Db[k] = b[k] * Dinv[k];
+        for (int k = 0; k < NX; ++k) xn_ext[perm(k)] = qn[k];
+    }
+};
+
+// examples/box_pivoting: a 1 m square box on the ground, pushed / pivoted by a position-controlled
+// disc ("hand", radius 0.1; examples/box_pivoting/analysis/box_pivoting_analysis.py:34-72).
+//   x = [x_h, x_b, y_h, y_b, th_b]   -- the reference's state order (box_pivoting_analysis.py:53-64)
+//   u = commanded hand position [x_h, y_h]              (indices_u_into_x = 0, 2)
+//   internally q = [xb, yb, th, xh, yh]
+//   params = {h, g, mass, half, mu, kp, r_hand, pgs_iters}   (box_pivoting_setup.py:9-19: Kp = 5e4,
+//            h = 0.1, g = 9.81; the box mass and the friction coefficient are in the absent SDF/YAML)
+// Contacts (2 friction generators each): the 4 box corners against the ground y = 0, the hand against
+// the box (closest point of the square's boundary; inside / on the boundary: the nearest face), the
+// hand against the ground.  PARITY UNPINNED, like the planar hand.
+struct BoxPivotModel {
+    static constexpr int NX = 5, NU = 2, NPARAMS = 8;
+    static constexpr int NC = 12;
+    static constexpr bool HAS_JACOBIAN = false;
+    IRS_HD static constexpr int perm(int k) { return k == 0 ? 1 : k == 1 ? 3 : k == 2 ? 4 : k == 3 ? 0 : 2; }
+    IRS_HD static int u_into_x(int j) { return perm(3 + j); }
+
+    template <typename S>
+    IRS_HD static void step(const ModelParams& p, const S* x_ext, const S* u, S* xn_ext) {
+        using T = typename scalar_of<S>::type;
+        const T h = T(p.v[0]), g = T(p.v[1]), mass = T(p.v[2]), a = T(p.v[3]), mu = T(p.v[4]);
+        const T kp = T(p.v[5]), rh = T(p.v[6]);
+        const int iters = (int)p.v[7];
+        S q[NX], qn[NX];
 #pragma unroll
-        for (int i = 0; i < NC; ++i) {
+        for (int k = 0; k < NX; ++k) q[k] = x_ext[perm(k)];
+        const T inertia = mass * (T(2) * a) * (T(2) * a) / T(6);     // square plate, side 2a
+        T Dinv[NX];
+        Dinv[0] = h * h / mass; Dinv[1] = h * h / mass; Dinv[2] = h * h / inertia;
+        Dinv[3] = T(1) / kp; Dinv[4] = T(1) / kp;
+        S b[NX];
+        b[0] = S(T(0)); b[1] = S(mass * g); b[2] = S(T(0));
+        b[3] = kp * (q[3] - u[0]); b[4] = kp * (q[4] - u[1]);
+
+        S J[NC][NX], phi[NC];
+        S sn, cs;
+        irs_sincos(q[2], sn, cs);
+        // rows 0..7: box corners (+-a, +-a) against the ground
 #pragma unroll
-            for (int k = 0; k < NX; ++k) JD[i][k] = J[i][k] * Dinv[k];
-            S ri = phi[i];
+        for (int c = 0; c < 4; ++c) {
+            const T lx = (c & 1) ? a : -a, ly = (c & 2) ? a : -a;
+            const S rx = cs * lx - sn * ly, ry = sn * lx + cs * ly;      // corner - centre, world frame
+            const S gap = q[1] + ry;
 #pragma unroll
-            for (int k = 0; k < NX; ++k) ri = ri - J[i][k] * Db[k];
-            r[i] = ri;
-            lam[i] = ri * T(0);
-#pragma unroll
-            for (int j = 0; j <= i; ++j) {
-                S w = JD[i][0] * J[j][0];
-#pragma unroll
-                for (int k = 1; k < NX; ++k) w = w + JD[i][k] * J[j][k];
-                W[i][j] = w;
-                W[j][i] = w;
-            }
-            invW[i] = S(T(1)) / W[i][i];
-        }
-        // projected Gauss-Seidel, fixed sweep count (deterministic, branch-free per sample), in
-        // residual form: g = r + W lam is kept up to date, so one update is
-        //   lam_i <- max(lam_i - g_i / W_ii, 0),  g += W[:,i] (lam_i_new - lam_i_old)
-        // -- a 4-deep dependent chain and 8 independent FMAs (4 packed ones in f32) instead of an
-        // 8-term dot product per update.
-        if constexpr (std::is_same<S, float>::value) {
-            typedef float f2 __attribute__((ext_vector_type(2)));
-            f2 Wc[NC][NC / 2], g2[NC / 2];
-#pragma unroll
-            for (int i = 0; i < NC; ++i)
-#pragma unroll
-                for (int k = 0; k < NC / 2; ++k) Wc[i][k] = f2{W[2 * k][i], W[2 * k + 1][i]};
-#pragma unroll
-            for (int k = 0; k < NC / 2; ++k) g2[k] = f2{r[2 * k], r[2 * k + 1]};
-            for (int it = 0; it < iters; ++it) {
-#pragma unroll
-                for (int i = 0; i < NC; ++i) {
-                    const float gi = (i & 1) ? g2[i / 2].y : g2[i / 2].x;
-                    const float nw = fmaxf(fmaf(-gi, invW[i], lam[i]), 0.f);
-                    const float dl = nw - lam[i];
-                    lam[i] = nw;
-                    const f2 d2 = f2{dl, dl};
-#pragma unroll
-                    for (int k = 0; k < NC / 2; ++k) g2[k] = Wc[i][k] * d2 + g2[k];
-                }
-            }
-        } else {
-            S g[NC];
-#pragma unroll
-            for (int i = 0; i < NC; ++i) g[i] = r[i];
-            for (int it = 0; it < iters; ++it) {
-#pragma unroll
-                for (int i = 0; i < NC; ++i) {
-                    const S nw = irs_max0(S(lam[i] - g[i] * invW[i]));
-                    const S dl = nw - lam[i];
-                    lam[i] = nw;
-#pragma unroll
-                    for (int j = 0; j < NC; ++j) g[j] = g[j] + W[j][i] * dl;
-                }
+            for (int gen = 0; gen < 2; ++gen) {
+                const int row = 2 * c + gen;
+                const T sg = gen == 0 ? mu : -mu;                       // e = n + sg t, n = (0,1), t = (1,0)
+                phi[row] = gap;
+                J[row][0] = S(sg);
+                J[row][1] = S(T(1));
+                J[row][2] = rx - ry * sg;                                // e . (z x r) = -e_x r_y + e_y r_x
+                J[row][3] = S(T(0));
+                J[row][4] = S(T(0));
             }
         }
+        // rows 8..9: hand against the box
+        {
+            const S dx = q[3] - q[0], dy = q[4] - q[1];
+            const S px = cs * dx + sn * dy, py = -sn * dx + cs * dy;     // hand centre in the box frame
+            const T pxv = irs_value(px), pyv = irs_value(py);
+            const bool outside = fabs(pxv) > a || fabs(pyv) > a;
+            // outside: nearest point = clamp; inside or on the boundary: the nearest face
+            const S cxq = irs_select(pxv > a, S(a), irs_select(pxv < -a, S(-a), px));
+            const S cyq = irs_select(pyv > a, S(a), irs_select(pyv < -a, S(-a), py));
+            const T ddx = a - fabs(pxv), ddy = a - fabs(pyv);           // penetration depths (inside)
+            const bool facex = ddx <= ddy;
+            const T sgx = pxv >= T(0) ? T(1) : T(-1), sgy = pyv >= T(0) ? T(1) : T(-1);
+            S qlx, qly, nlx, nly, dist;
+            if (outside) {
+                const S ex = px - cxq, ey = py - cyq;
+                dist = irs_sqrt(ex * ex + ey * ey);
+                nlx = ex / dist; nly = ey / dist;
+                qlx = cxq; qly = cyq;
+            } else {
+                qlx = facex ? S(sgx * a) : px;
+                qly = facex ? py : S(sgy * a);
+                nlx = S(facex ? sgx : T(0));
+                nly = S(facex ? T(0) : sgy);
+                dist = S(-(facex ? ddx : ddy));
+            }
+            const S gap = dist - rh;
+            const S nx = cs * nlx - sn * nly, ny = sn * nlx + cs * nly;  // box -> hand, world frame
+            const S rx = cs * qlx - sn * qly, ry = sn * qlx + cs * qly;  // contact point - box centre
 #pragma unroll
-        for (int k = 0; k < NX; ++k) {
-            S f = -b[k];
-#pragma unroll
-            for (int i = 0; i < NC; ++i) f = f + J[i][k] * lam[i];
-            qn[k] = q[k] + f * Dinv[k];
+            for (int gen = 0; gen < 2; ++gen) {
+                const int row = 8 + gen;
+                const T sg = gen == 0 ? mu : -mu;
+                const S ex = nx - ny * sg, ey = ny + nx * sg;            // e = n + sg t, t = (-ny, nx)
+                phi[row] = gap;
+                J[row][0] = -ex;
+                J[row][1] = -ey;
+                J[row][2] = -(ey * rx - ex * ry);
+                J[row][3] = ex;
+                J[row][4] = ey;
+            }
         }
+        // rows 10..11: hand against the ground
+#pragma unroll
+        for (int gen = 0; gen < 2; ++gen) {
+            const int row = 10 + gen;
+            const T sg = gen == 0 ? mu : -mu;
+            phi[row] = q[4] - rh;
+            J[row][0] = S(T(0)); J[row][1] = S(T(0)); J[row][2] = S(T(0));
+            J[row][3] = S(sg);
+            J[row][4] = S(T(1));
+        }
+        irs_contact_qp_step<S, NX, NC>(q, Dinv, b, J, phi, iters, qn);
 #pragma unroll
         for (int k = 0; k < NX; ++k) xn_ext[perm(k)] = qn[k];
     }

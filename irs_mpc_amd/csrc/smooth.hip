@@ -57,7 +57,7 @@ struct SmoothTraits {
     // last-arriver reduction: NGRP groups of P lanes each sum a strided subset of blocks
     static constexpr int NGRP = (P >= kBlock) ? 1 : kBlock / P;
     // light = few accumulators AND a small functor: fits 1024-thread workgroups (128 VGPRs)
-    static constexpr bool LIGHT = PP <= 32 && d <= 7;
+    static constexpr bool LIGHT = PP <= 32 && d <= 7 && Model::HAS_JACOBIAN;   // contact steps are never light
 };
 
 struct SmoothArgs {
@@ -740,6 +740,7 @@ bool is_light(int model, int mode) {
         case IRS_MODEL_BICYCLE: return light_m<BicycleModel>(mode);
         case IRS_MODEL_THREE_CART: return light_m<ThreeCartModel>(mode);
         case IRS_MODEL_PLANAR_HAND: return light_m<PlanarHandModel>(mode);
+        case IRS_MODEL_BOX_PIVOT: return light_m<BoxPivotModel>(mode);
     }
     return false;
 }

@@ -1,8 +1,8 @@
 """Device-backed twins of the reference's analytic example plugins."""
 import numpy as np
 
-from ._lib import (MODEL_BICYCLE, MODEL_PENDULUM, MODEL_PLANAR_HAND, MODEL_QUADROTOR,
-                   MODEL_THREE_CART)
+from ._lib import (MODEL_BICYCLE, MODEL_BOX_PIVOT, MODEL_PENDULUM, MODEL_PLANAR_HAND,
+                   MODEL_QUADROTOR, MODEL_THREE_CART)
 from .dynamical_system import DynamicalSystem
 
 
@@ -67,39 +67,15 @@ class ThreeCartDynamics(DynamicalSystem):
         return [self.h, self.d]
 
 
-class PlanarHandDynamics(DynamicalSystem):
-    """Device twin of `QuasistaticDynamics` (irs_lqr/quasistatic_dynamics.py:15-164) for the
-    planar hand of examples/planar_hand (planar_hand_setup.py:8-27): a disc cradled by two
-    2-link arms, x = [xo, ql1, qr1, yo, ql2, qr2, th] (the reference's order), u = commanded joint
-    angles [ql1, ql2, qr1, qr2].  Steps the
-    Anitescu convex quasi-dynamic QP on the device (csrc/contact_models.hpp); the reference steps
-    the external quasistatic_simulator, so parity for this model is UNPINNED.  No Jacobian:
-    `jacobian_xu*` raise, `ZERO_ORDER_B` smoothing returns the decoupled (A,B)."""
-    device_model = MODEL_PLANAR_HAND
+class QuasistaticDeviceDynamics(DynamicalSystem):
+    """What `QuasistaticDynamics` (irs_lqr/quasistatic_dynamics.py:15-164) offers besides the step:
+    the bookkeeping it derives from the plant (:22-28), keyed by model NAME here (the reference keys
+    by ModelInstanceIndex).  Subclasses set `models_unactuated`, `models_actuated`,
+    `position_indices` and a device functor without a Jacobian: `jacobian_xu*` raise, `ZERO_ORDER_B`
+    smoothing returns the decoupled (A,B)."""
 
-    def __init__(self, h, mass=1.0, mu=0.5, pgs_iters=50):
-        super().__init__()
-        self.h = h
-        self.dim_x = 7
-        self.dim_u = 4
-        self.g = 10.0            # planar_hand_setup.py:23
-        self.mass = mass
-        self.R = 0.25            # planar_hand_setup.py:8
-        self.mu = mu
-        self.kp = (50.0, 25.0)   # planar_hand_setup.py:12
-        self.l1, self.l2 = 0.3, 0.2
-        self.r_link = 0.05
-        self.base_x = 0.1
-        self.pgs_iters = pgs_iters
-
-        # the bookkeeping QuasistaticDynamics derives from the plant (quasistatic_dynamics.py:22-28),
-        # keyed by model NAME here (the reference keys by ModelInstanceIndex)
-        self.models_unactuated = ["sphere"]
-        self.models_actuated = ["arm_left", "arm_right"]
+    def _finish_bookkeeping(self):
         self.models_all = self.models_unactuated + self.models_actuated
-        # the reference's state order (planar_hand_analysis.py:61-67): x = [xo, ql1, qr1, yo, ql2, qr2, th]
-        self.position_indices = {"sphere": np.array([0, 3, 6]), "arm_left": np.array([1, 4]),
-                                 "arm_right": np.array([2, 5])}
         self.velocity_indices = self.position_indices
 
     # ---- quasistatic_dynamics.py:57-130: vector <-> per-model dict helpers --------------
@@ -144,6 +120,70 @@ class PlanarHandDynamics(DynamicalSystem):
     def publish_trajectory(self, x_traj):
         """quasistatic_dynamics.py:132-135 animates in meshcat; there is no visualiser here."""
 
+
+
+class PlanarHandDynamics(QuasistaticDeviceDynamics):
+    """Device twin of `QuasistaticDynamics` (irs_lqr/quasistatic_dynamics.py:15-164) for the
+    planar hand of examples/planar_hand (planar_hand_setup.py:8-27): a disc cradled by two
+    2-link arms, x = [xo, ql1, qr1, yo, ql2, qr2, th] (the reference's order), u = commanded joint
+    angles [ql1, ql2, qr1, qr2].  Steps the
+    Anitescu convex quasi-dynamic QP on the device (csrc/contact_models.hpp); the reference steps
+    the external quasistatic_simulator, so parity for this model is UNPINNED.  No Jacobian:
+    `jacobian_xu*` raise, `ZERO_ORDER_B` smoothing returns the decoupled (A,B)."""
+    device_model = MODEL_PLANAR_HAND
+
+    def __init__(self, h, mass=1.0, mu=0.5, pgs_iters=50):
+        super().__init__()
+        self.h = h
+        self.dim_x = 7
+        self.dim_u = 4
+        self.g = 10.0            # planar_hand_setup.py:23
+        self.mass = mass
+        self.R = 0.25            # planar_hand_setup.py:8
+        self.mu = mu
+        self.kp = (50.0, 25.0)   # planar_hand_setup.py:12
+        self.l1, self.l2 = 0.3, 0.2
+        self.r_link = 0.05
+        self.base_x = 0.1
+        self.pgs_iters = pgs_iters
+
+        # the bookkeeping QuasistaticDynamics derives from the plant (quasistatic_dynamics.py:22-28),
+        # keyed by model NAME here (the reference keys by ModelInstanceIndex)
+        self.models_unactuated = ["sphere"]
+        self.models_actuated = ["arm_left", "arm_right"]
+        # the reference's state order (planar_hand_analysis.py:61-67): x = [xo, ql1, qr1, yo, ql2, qr2, th]
+        self.position_indices = {"sphere": np.array([0, 3, 6]), "arm_left": np.array([1, 4]),
+                                 "arm_right": np.array([2, 5])}
+        self._finish_bookkeeping()
+
     def device_params(self):
         return [self.h, self.g, self.mass, self.R, self.mu, self.kp[0], self.kp[1], self.l1, self.l2,
                 self.r_link, self.base_x, float(self.pgs_iters)]
+
+
+class BoxPivotingDynamics(QuasistaticDeviceDynamics):
+    """Device twin of `QuasistaticDynamics` for examples/box_pivoting (box_pivoting_setup.py:6-19,
+    run_box_pivoting.py:20-75): a 1 m square box on the ground, pivoted by a position-controlled disc.
+    x = [x_h, x_b, y_h, y_b, th_b] (the reference's order, analysis/box_pivoting_analysis.py:53-64),
+    u = commanded hand position.  Same contact scheme as the planar hand; parity UNPINNED."""
+    device_model = MODEL_BOX_PIVOT
+
+    def __init__(self, h, mass=1.0, mu=0.5, pgs_iters=50):
+        super().__init__()
+        self.h = h
+        self.dim_x = 5
+        self.dim_u = 2
+        self.g = 9.81            # box_pivoting_setup.py:19
+        self.mass = mass
+        self.half = 0.5          # box_1m_rotation.sdf (box_pivoting_setup.py:6)
+        self.mu = mu
+        self.kp = 50000.0        # box_pivoting_setup.py:10
+        self.r_hand = 0.1        # analysis/box_pivoting_analysis.py:61
+        self.pgs_iters = pgs_iters
+        self.models_unactuated = ["box"]
+        self.models_actuated = ["hand"]
+        self.position_indices = {"box": np.array([1, 3, 4]), "hand": np.array([0, 2])}
+        self._finish_bookkeeping()
+
+    def device_params(self):
+        return [self.h, self.g, self.mass, self.half, self.mu, self.kp, self.r_hand, float(self.pgs_iters)]

@@ -278,7 +278,52 @@ class ThreeCartOracle:
         return np.stack([self.jacobian_xu(x[i], u[i]) for i in range(x.shape[0])])
 
 
-class PlanarHandOracle:
+class _ContactQPOracle:
+    """Shared tail of the contact oracles: subclasses provide `_qp(x, u)` -> (Dinv, b, J, phi) in
+    their INTERNAL coordinate order and `PERM` (internal index -> index in the reference's x)."""
+
+    def dynamics_batch(self, x, u):
+        Dinv, b, J, phi = self._qp(x, u)
+        nc = J.shape[1]
+        W = np.einsum("bik,k,bjk->bij", J, Dinv, J)
+        r = phi - np.einsum("bik,k,bk->bi", J, Dinv, b)
+        lam = np.zeros_like(r)
+        invW = 1.0 / np.einsum("bii->bi", W)
+        g = r.copy()                               # residual g = r + W lam, kept up to date
+        for _ in range(int(self.pgs_iters)):
+            for i in range(nc):
+                new = np.maximum(lam[:, i] - g[:, i] * invW[:, i], 0.0)
+                g += W[:, :, i] * (new - lam[:, i])[:, None]
+                lam[:, i] = new
+        out = np.array(np.atleast_2d(x), dtype=float)
+        out[:, self.PERM] += (np.einsum("bik,bi->bk", J, lam) - b) * Dinv
+        return out
+
+    def dynamics(self, x, u):
+        return self.dynamics_batch(x[None], u[None])[0]
+
+    def dynamics_exact(self, x, u):
+        """The same QP solved to optimality (L-BFGS-B on the dual): the physics check of the
+        fixed-sweep PGS."""
+        from scipy.optimize import minimize
+        Dinv, b, J, phi = self._qp(x, u)
+        b, J, phi = b[0], J[0], phi[0]
+        W = (J * Dinv).dot(J.T)
+        r = phi - (J * Dinv).dot(b)
+        res = minimize(lambda l: 0.5 * l.dot(W).dot(l) + r.dot(l), np.zeros(len(r)), jac=lambda l: W.dot(l) + r,
+                       bounds=[(0, None)] * len(r), method="L-BFGS-B",
+                       options={"ftol": 1e-15, "gtol": 1e-12, "maxiter": 10000})
+        out = np.array(x, dtype=float)
+        out[self.PERM] += (J.T.dot(res.x) - b) * Dinv
+        return out
+
+    def jacobian_xu(self, x, u):
+        raise NotImplementedError("no differentiable step; see zero_order_B_decoupled")
+
+    jacobian_xu_batch = jacobian_xu
+
+
+class PlanarHandOracle(_ContactQPOracle):
     """Planar quasi-dynamic contact step for examples/planar_hand (call sites
     irs_lqr/quasistatic_dynamics.py:136-164; set-up examples/planar_hand/planar_hand_setup.py:8-27;
     geometry examples/planar_hand/analysis/planar_hand_analysis.py:33-101).
@@ -376,44 +421,87 @@ class PlanarHandOracle:
                     J[:, row, 4 + 2 * arm] = j2
         return Dinv, b, J, phi
 
-    def dynamics_batch(self, x, u):
-        Dinv, b, J, phi = self._qp(x, u)
-        W = np.einsum("bik,k,bjk->bij", J, Dinv, J)
-        r = phi - np.einsum("bik,k,bk->bi", J, Dinv, b)
-        lam = np.zeros_like(r)
-        invW = 1.0 / np.einsum("bii->bi", W)
-        g = r.copy()                               # residual g = r + W lam, kept up to date
-        for _ in range(int(self.pgs_iters)):
-            for i in range(8):
-                new = np.maximum(lam[:, i] - g[:, i] * invW[:, i], 0.0)
-                g += W[:, :, i] * (new - lam[:, i])[:, None]
-                lam[:, i] = new
-        out = np.array(np.atleast_2d(x), dtype=float)
-        out[:, self.PERM] += (np.einsum("bik,bi->bk", J, lam) - b) * Dinv
-        return out
 
-    def dynamics(self, x, u):
-        return self.dynamics_batch(x[None], u[None])[0]
 
-    def dynamics_exact(self, x, u):
-        """The same QP solved to optimality: the dual min 1/2|D^-1/2 (J' lam - b)|^2 + phi' lam,
-        lam >= 0, is an NNLS problem after completing the square on range(J D^-1/2)."""
-        from scipy.optimize import minimize
-        Dinv, b, J, phi = self._qp(x, u)
-        Dinv, b, J, phi = Dinv, b[0], J[0], phi[0]
-        W = (J * Dinv).dot(J.T)
-        r = phi - (J * Dinv).dot(b)
-        res = minimize(lambda l: 0.5 * l.dot(W).dot(l) + r.dot(l), np.zeros(8), jac=lambda l: W.dot(l) + r,
-                       bounds=[(0, None)] * 8, method="L-BFGS-B", options={"ftol": 1e-15, "gtol": 1e-12,
-                                                                             "maxiter": 10000})
-        out = np.array(x, dtype=float)
-        out[self.PERM] += (J.T.dot(res.x) - b) * Dinv
-        return out
+class BoxPivotOracle(_ContactQPOracle):
+    """examples/box_pivoting (box_pivoting_setup.py:6-19, run_box_pivoting.py:20-75): a 1 m square box
+    on the ground y = 0, pivoted by a position-controlled disc of radius 0.1 (analysis/
+    box_pivoting_analysis.py:34-72).  Reference state order x = [x_h, x_b, y_h, y_b, th_b]
+    (box_pivoting_analysis.py:53-64), u = commanded hand position, indices_u_into_x = [0, 2];
+    internally q = x[PERM] = [xb, yb, th, xh, yh].  Contacts (2 friction generators each): the 4 box
+    corners vs the ground, the hand vs the box (closest boundary point; inside or on the boundary:
+    the nearest face), the hand vs the ground.  Same scheme as PlanarHandOracle; PARITY UNPINNED
+    (box mass and friction live in the absent box_1m_rotation.sdf / box_pivoting.yml)."""
 
-    def jacobian_xu(self, x, u):
-        raise NotImplementedError("no differentiable step; see zero_order_B_decoupled")
+    PERM = np.array([1, 3, 4, 0, 2])
 
-    jacobian_xu_batch = jacobian_xu
+    def __init__(self, h, mass=1.0, mu=0.5, pgs_iters=50):
+        self.h = h
+        self.dim_x, self.dim_u = 5, 2
+        self.g = 9.81
+        self.mass, self.half, self.mu = mass, 0.5, mu
+        self.kp = 50000.0
+        self.r_hand = 0.1
+        self.pgs_iters = pgs_iters
+        self.indices_u_into_x = self.PERM[3:].copy()
+
+    @classmethod
+    def pack(cls, box, hand):
+        x = np.zeros(5)
+        x[cls.PERM] = np.concatenate([box, hand])
+        return x
+
+    def params(self):
+        return [self.h, self.g, self.mass, self.half, self.mu, self.kp, self.r_hand, self.pgs_iters]
+
+    def _qp(self, q, u):
+        q = np.atleast_2d(q)[:, self.PERM]
+        u = np.atleast_2d(u)
+        B = q.shape[0]
+        h, m, a, mu, kp, rh = self.h, self.mass, self.half, self.mu, self.kp, self.r_hand
+        inertia = m * (2 * a) ** 2 / 6.0
+        Dinv = np.array([h * h / m, h * h / m, h * h / inertia, 1 / kp, 1 / kp])
+        b = np.zeros((B, 5))
+        b[:, 1] = m * self.g
+        b[:, 3] = kp * (q[:, 3] - u[:, 0])
+        b[:, 4] = kp * (q[:, 4] - u[:, 1])
+        J, phi = np.zeros((B, 12, 5)), np.zeros((B, 12))
+        sn, cs = np.sin(q[:, 2]), np.cos(q[:, 2])
+        for c in range(4):
+            lx, ly = (a if c & 1 else -a), (a if c & 2 else -a)
+            rx, ry = cs * lx - sn * ly, sn * lx + cs * ly
+            for gen in range(2):
+                row, sg = 2 * c + gen, (mu if gen == 0 else -mu)
+                phi[:, row] = q[:, 1] + ry
+                J[:, row, 0], J[:, row, 1], J[:, row, 2] = sg, 1.0, rx - ry * sg
+        dx, dy = q[:, 3] - q[:, 0], q[:, 4] - q[:, 1]
+        px, py = cs * dx + sn * dy, -sn * dx + cs * dy
+        outside = (np.abs(px) > a) | (np.abs(py) > a)
+        cxq, cyq = np.clip(px, -a, a), np.clip(py, -a, a)
+        ddx, ddy = a - np.abs(px), a - np.abs(py)
+        facex = ddx <= ddy
+        sgx, sgy = np.where(px >= 0, 1.0, -1.0), np.where(py >= 0, 1.0, -1.0)
+        ex, ey = px - cxq, py - cyq
+        d_out = np.sqrt(ex * ex + ey * ey)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            nlx = np.where(outside, ex / d_out, np.where(facex, sgx, 0.0))
+            nly = np.where(outside, ey / d_out, np.where(facex, 0.0, sgy))
+        qlx = np.where(outside, cxq, np.where(facex, sgx * a, px))
+        qly = np.where(outside, cyq, np.where(facex, py, sgy * a))
+        dist = np.where(outside, d_out, -np.where(facex, ddx, ddy))
+        nx, ny = cs * nlx - sn * nly, sn * nlx + cs * nly
+        rx, ry = cs * qlx - sn * qly, sn * qlx + cs * qly
+        for gen in range(2):
+            row, sg = 8 + gen, (mu if gen == 0 else -mu)
+            e_x, e_y = nx - ny * sg, ny + nx * sg
+            phi[:, row] = dist - rh
+            J[:, row, 0], J[:, row, 1], J[:, row, 2] = -e_x, -e_y, -(e_y * rx - e_x * ry)
+            J[:, row, 3], J[:, row, 4] = e_x, e_y
+        for gen in range(2):
+            row, sg = 10 + gen, (mu if gen == 0 else -mu)
+            phi[:, row] = q[:, 4] - rh
+            J[:, row, 3], J[:, row, 4] = sg, 1.0
+        return Dinv, b, J, phi
 
 
 def zero_order_B_decoupled(system, x_trj, u_trj, du):
@@ -435,7 +523,7 @@ def zero_order_B_decoupled(system, x_trj, u_trj, du):
 
 
 SYSTEMS = {"pendulum": PendulumOracle, "quadrotor": QuadrotorOracle, "bicycle": BicycleOracle,
-           "three_cart": ThreeCartOracle, "planar_hand": PlanarHandOracle}
+           "three_cart": ThreeCartOracle, "planar_hand": PlanarHandOracle, "box_pivoting": BoxPivotOracle}
 
 
 # --------------------------------------------------------------------------

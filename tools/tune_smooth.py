@@ -17,9 +17,10 @@ from irs_mpc_amd import PendulumDynamics, QuadrotorDynamics, device as dev, _lib
 model, mode_s, T, N = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 rng_mode = len(sys.argv) > 5 and "rng" in sys.argv[5:]
 fuse = "nofuse" not in sys.argv[5:]
-from irs_mpc_amd import BicycleDynamics, PlanarHandDynamics, ThreeCartDynamics  # noqa: E402
+from irs_mpc_amd import BicycleDynamics, BoxPivotingDynamics, PlanarHandDynamics, ThreeCartDynamics  # noqa: E402
 sysd = {"pendulum": PendulumDynamics(0.05), "quadrotor": QuadrotorDynamics(0.05), "bicycle": BicycleDynamics(0.1),
-        "three_cart": ThreeCartDynamics(0.05), "planar_hand": PlanarHandDynamics(0.1)}[model]
+        "three_cart": ThreeCartDynamics(0.05), "planar_hand": PlanarHandDynamics(0.1),
+        "box_pivoting": BoxPivotingDynamics(0.1)}[model]
 mode = {"zero": _lib.SMOOTH_ZERO_ORDER_AB, "first": _lib.SMOOTH_FIRST_ORDER, "zeroB": _lib.SMOOTH_ZERO_ORDER_B}[mode_s]
 dm = sysd.dm()
 n, m = dm.n, dm.m
@@ -30,6 +31,9 @@ x0 = np.zeros(n)
 if model == "planar_hand":      # examples/planar_hand/run_planar_hand.py:31-44
     x0 = sysd.get_x_from_q_dict({"sphere": [0.0, 0.35, 0.0], "arm_left": [-np.pi / 4] * 2, "arm_right": [np.pi / 4] * 2})
     u_trj = dev.to_dev(np.tile(x0[sysd.get_u_indices_into_x()], (T, 1)))
+if model == "box_pivoting":     # examples/box_pivoting/run_box_pivoting.py:20-43 (hand sweeping to the right)
+    x0 = sysd.get_x_from_q_dict({"box": [0.0, 0.5, 0.0], "hand": [-0.5, 0.5]})
+    u_trj = dev.to_dev(np.stack([np.array([-0.5 + (t + 1.0) / T, 0.5]) for t in range(T)]))
 Q, R = dev.to_dev(np.eye(n)), dev.to_dev(np.eye(m))
 xd = dev.to_dev(np.zeros((T + 1, n)))
 x_trj, _ = dm.rollout_cost(dev.to_dev(x0), u_trj, Q, R, xd)
