@@ -108,10 +108,14 @@ int irs_evaluate_cost(int n, int m, int T, const double *x_trj, const double *u_
 
 /* ---- Randomised-smoothing linearisation (get_TV_matrices) -------------------- */
 
-/* Length P of one timestep's sufficient statistics:
+/* Length P of one timestep's sufficient statistics (z = the perturbed components, d = n+m):
  *   ZERO_ORDER_AB: d(d+1)/2 (upper Gram of z=[dx,du]) + d*n (z (f(x+dx,u+du)-f(x,u))')
  *   FIRST_ORDER  : n*d      (sum of Jacobians)
- *   ZERO_ORDER_B : m(m+1)/2 + m*n                                  (d = n+m)      */
+ *   ZERO_ORDER_B : m(m+1)/2 + m*n                                  (z = du)
+ * Contact models (IRS_MODEL_PLANAR_HAND, IRS_MODEL_BOX_PIVOT; expensive step) use the layout
+ *   [Gram | z (f(x+dx,u+du) - xb)' | sum of z],  P as above + d (resp. m),
+ * xb = the f32-rounded x_t: the finalize step subtracts (sum z)(f(x,u) - xb)' with f(x,u) in f64, so
+ * no lane of the sample pass evaluates the nominal step.  Sums of shards add in either layout.    */
 int irs_sums_len(int model, int mode);
 
 /* Bytes of DEV scratch the irs_smooth* calls need for (T, N) (T <= 1024).        */

@@ -52,7 +52,14 @@ struct SmoothTraits {
     static constexpr int NZ = (MODE == IRS_SMOOTH_ZERO_ORDER_B) ? m : d;
     static constexpr int Z0 = (MODE == IRS_SMOOTH_ZERO_ORDER_B) ? n : 0;  // first one
     static constexpr int NG = NZ * (NZ + 1) / 2;
-    static constexpr int P = (MODE == IRS_SMOOTH_FIRST_ORDER) ? n * d : NG + NZ * n;
+    // zero-order statistics: upper Gram of z and z df'.  Models with an expensive step (contact QPs)
+    // take df = f(x+dx,u+du) - xb and append sum(z): the solve then subtracts the nominal step,
+    // (sum z)(f(x,u) - xb)', so that no lane of the sample pass has to evaluate f(x,u) (one whole
+    // sample evaluation per lane otherwise).  Cheap analytic steps keep df = f(..) - f(x,u): for them
+    // the three extra accumulators cost more than the nominal evaluation (measured, pendulum).
+    static constexpr bool SUMZ = MODE != IRS_SMOOTH_FIRST_ORDER && !Model::HAS_JACOBIAN;
+    static constexpr int NH = NG + NZ * n;     // offset of the sum-of-z block
+    static constexpr int P = (MODE == IRS_SMOOTH_FIRST_ORDER) ? n * d : NG + NZ * n + (SUMZ ? NZ : 0);
     static constexpr int PP = irs_reduce_pad(P);
     // last-arriver reduction: NGRP groups of P lanes each sum a strided subset of blocks
     static constexpr int NGRP = (P >= kBlock) ? 1 : kBlock / P;
@@ -131,6 +138,7 @@ struct FinalizeLds {
     double G[TR::NZ][TR::NZ + 1];
     double H[TR::NZ][TR::n];
     double sc[TR::NZ];
+    double fd[TR::n];            // f(x_t,u_t) - (the f32-rounded) x_t
     double AB[TR::n][TR::d];
     int bad;
 };
@@ -203,10 +211,15 @@ __device__ __forceinline__ void finalize_timestep(const ModelParams& p, const do
                     g[i][j] = S[i * NZ - i * (i - 1) / 2 + (j - i)];
                     g[j][i] = g[i][j];
                 }
+            // H = sum z (f(x+dx,u+du) - f(x,u))' = sum z (f(..) - xb)' - (sum z)(f(x,u) - xb)', xb = the
+            // f32-rounded nominal state the sample pass subtracted
 #pragma unroll
             for (int i = 0; i < NZ; ++i)
 #pragma unroll
-                for (int k = 0; k < n; ++k) h[i][k] = S[TR::NG + i * n + k];
+                for (int k = 0; k < n; ++k) {
+                    h[i][k] = S[TR::NG + i * n + k];
+                    if constexpr (TR::SUMZ) h[i][k] -= S[TR::NH + i] * (f[k] - (double)(float)x[k]);
+                }
 #pragma unroll
             for (int i = 0; i < NZ; ++i) {
                 bool pos = g[i][i] > 0.0;
@@ -262,7 +275,16 @@ __device__ __forceinline__ void finalize_timestep(const ModelParams& p, const do
             int r = i < j ? i : j, c = i < j ? j : i;
             L.G[i][j] = S[r * NZ - r * (r - 1) / 2 + (c - r)];
         }
-        for (int q = lane; q < NZ * n; q += 64) L.H[q / n][q % n] = S[TR::NG + q];
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < n; ++k) L.fd[k] = f[k] - (double)(float)x[k];
+        }
+        wave_sync();
+        for (int q = lane; q < NZ * n; q += 64) {
+            double hq = S[TR::NG + q];
+            if constexpr (TR::SUMZ) hq -= S[TR::NH + q / n] * L.fd[q % n];
+            L.H[q / n][q % n] = hq;
+        }
         wave_sync();
         // Jacobi scaling: G' = D G D, H' = D H, D = diag(G)^-1/2
         if (lane < NZ) {
@@ -362,7 +384,12 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
     for (int i = 0; i < n; ++i) xb[i] = (float)a.x_trj[(size_t)t * n + i];
 #pragma unroll
     for (int j = 0; j < m; ++j) ub[j] = (float)a.u_trj[(size_t)t * m + j];
-    if constexpr (MODE != IRS_SMOOTH_FIRST_ORDER) Model::template step<float>(a.p, xb, ub, f0);
+    // what the samples' f(x+dx,u+du) is measured from: the nominal step, or (TR::SUMZ) just xb
+    if constexpr (MODE != IRS_SMOOTH_FIRST_ORDER && !TR::SUMZ) Model::template step<float>(a.p, xb, ub, f0);
+    else {
+#pragma unroll
+        for (int i = 0; i < n; ++i) f0[i] = xb[i];
+    }
 
     // workgroup 0 owns [0, chunk0), workgroup b >= 1 owns chunk0 + [(b-1) chunk, b chunk)
     const int s_begin = blk == 0 ? 0 : a.chunk0 + (blk - 1) * a.chunk;
@@ -412,7 +439,11 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
             for (int j = 0; j < m; ++j) us[j] = ub[j] + z[n + j];
             Model::template step<float>(a.p, xs, us, fx);
 #pragma unroll
-            for (int k = 0; k < n; ++k) dfp[k] = fx[k] - f0[k];      // 0 for a zeroed slot
+            for (int k = 0; k < n; ++k) dfp[k] = fx[k] - f0[k];      // (!SUMZ: 0 for a zeroed slot)
+            if constexpr (TR::SUMZ) {
+                static_assert(!TR::SUMZ || n < 16, "column n of the dF tile carries the ones that sum z");
+                dfp[n < 16 ? n : 0] = 1.f;                           // z of an invalid slot is 0
+            }
             float4* rowp = reinterpret_cast<float4*>(my + lane * TS);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -435,6 +466,9 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
             const int i = 4 * rg + r, j = col;
             if (i < d && j < d && i <= j) red[wave * TR::PP + i * d - i * (i - 1) / 2 + (j - i)] = aG[r];
             if (i < d && j < n) red[wave * TR::PP + TR::NG + i * n + j] = aH[r];
+            if constexpr (TR::SUMZ) {
+                if (i < d && j == n) red[wave * TR::PP + TR::NH + i] = aH[r];
+            }
         }
     } else {
         float acc[TR::PP];
@@ -506,6 +540,10 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
                     for (int i = 0; i < NZ; ++i)
 #pragma unroll
                         for (int k = 0; k < n; ++k) { acc[q] = fmaf(z[Z0 + i], df[k], acc[q]); ++q; }
+                    if constexpr (TR::SUMZ) {
+#pragma unroll
+                        for (int i = 0; i < NZ; ++i) { acc[q] += z[Z0 + i]; ++q; }
+                    }
                 }
             }
         }

@@ -834,18 +834,23 @@ def device_gaussian_samples(T, N, n, m, std_x, std_u, seed, it,
 # sums of disjoint sample subsets ADD.  Used by tests to check the sharding /
 # all-reduce logic and the device `sums` buffers.
 # --------------------------------------------------------------------------
-def zero_order_sums(system, x_trj, u_trj, dx, du):
-    """(T,P) with P = d(d+1)/2 + d*n: upper-triangular Gram of z=[dx|du] followed
-    by z (f(x+dx,u+du)-f(x,u))', row-major -- the layout of irs_hip.h `sums`."""
+def zero_order_sums(system, x_trj, u_trj, dx, du, sum_z=False):
+    """(T,P), the layout of irs_hip.h `sums`: upper-triangular Gram of z=[dx|du] followed by z df'
+    row-major, df = f(x+dx,u+du) - f(x,u).  sum_z=True (the contact models' layout): df = f(..) - xb,
+    xb = the nominal state rounded to f32, and sum(z) is appended."""
     T, n, m = u_trj.shape[0], system.dim_x, system.dim_u
     d = n + m
     iu = np.triu_indices(d)
-    out = np.zeros((T, d * (d + 1) // 2 + d * n))
+    ng = len(iu[0])
+    out = np.zeros((T, ng + d * n + (d if sum_z else 0)))
     for t in range(T):
         z = np.hstack((dx[t], du[t]))
-        df = system.dynamics_batch(x_trj[t] + dx[t], u_trj[t] + du[t]) - system.dynamics(x_trj[t], u_trj[t])
-        out[t, :len(iu[0])] = (z.T @ z)[iu]
-        out[t, len(iu[0]):] = (z.T @ df).ravel()
+        ref = x_trj[t].astype(np.float32).astype(np.float64) if sum_z else system.dynamics(x_trj[t], u_trj[t])
+        df = system.dynamics_batch(x_trj[t] + dx[t], u_trj[t] + du[t]) - ref
+        out[t, :ng] = (z.T @ z)[iu]
+        out[t, ng:ng + d * n] = (z.T @ df).ravel()
+        if sum_z:
+            out[t, ng + d * n:] = z.sum(axis=0)
     return out
 
 
@@ -854,15 +859,19 @@ def zero_order_from_sums(system, x_trj, u_trj, sums):
     d = n + m
     iu = np.triu_indices(d)
     ng = len(iu[0])
+    sum_z = sums.shape[1] == ng + d * n + d
     At, Bt, ct = np.zeros((T, n, n)), np.zeros((T, n, m)), np.zeros((T, n))
     for t in range(T):
         G = np.zeros((d, d))
         G[iu] = sums[t, :ng]
         G = G + np.triu(G, 1).T
-        H = sums[t, ng:].reshape(d, n)
+        f = system.dynamics(x_trj[t], u_trj[t])
+        H = sums[t, ng:ng + d * n].reshape(d, n)
+        if sum_z:
+            H = H - np.outer(sums[t, ng + d * n:], f - x_trj[t].astype(np.float32).astype(np.float64))
         AB = np.linalg.solve(G, H).T
         At[t], Bt[t] = AB[:, :n], AB[:, n:]
-        ct[t] = system.dynamics(x_trj[t], u_trj[t]) - At[t].dot(x_trj[t]) - Bt[t].dot(u_trj[t])
+        ct[t] = f - At[t].dot(x_trj[t]) - Bt[t].dot(u_trj[t])
     return At, Bt, ct
 
 

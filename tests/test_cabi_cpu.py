@@ -43,6 +43,8 @@ def test_model_registry(lib):
     # P = d(d+1)/2 + d n  |  n d  |  m(m+1)/2 + m n
     assert [lib.irs_sums_len(0, mode) for mode in range(3)] == [12, 6, 3]
     assert [lib.irs_sums_len(1, mode) for mode in range(3)] == [136 + 192, 192, 10 + 48]
+    # contact models append sum(z): planar hand d = 11, m = 4
+    assert [lib.irs_sums_len(4, mode) for mode in (0, 2)] == [66 + 77 + 11, 10 + 28 + 4]
     assert lib.irs_sums_len(0, 7) == -1
     assert lib.irs_smooth_workspace_bytes(0, 0, 30, 10000) > 0
 

@@ -1073,3 +1073,39 @@ def test_box_pivot_quasistatic_iteration_vs_oracle(amd):
     np.testing.assert_allclose(float(out["cost"].item()), orc.eval_cost_quasistatic(xa, ua, xd, Q, Qd, R, idx), rtol=1e-7)
     # the horizon of the reference's script (T = 120) fits the LDS-resident solver for this model
     assert dm.quasistatic_descent_supported(120, 2)
+
+
+def test_contact_model_sums_layout_vs_oracle(amd):
+    """Contact models ship [Gram | z (f - xb)' | sum z] (include/irs_hip.h): the two-stage path
+    (accumulate -> finalize), the fused launch and the oracle's restatement of the layout agree, in
+    ZERO_ORDER_AB (x and u noise, MFMA Gram path) as well as ZERO_ORDER_B."""
+    from irs_mpc_amd import device as dev
+    from irs_mpc_amd._lib import SMOOTH_ZERO_ORDER_AB, SMOOTH_ZERO_ORDER_B
+    T, N = 5, 3000
+    sys_d, sys_o, x0, u_trj = _hand_setup(amd, T)
+    x_trj = orc.rollout(sys_o, x0, u_trj)
+    rng = np.random.default_rng(17)
+    dx = (rng.normal(size=(T, N, 7)) * 0.01).astype(np.float32)
+    du = (rng.normal(size=(T, N, 4)) * 0.1).astype(np.float32)
+    dm = sys_d.dm()
+    xd, ud = dev.to_dev(x_trj), dev.to_dev(u_trj)
+    so = orc.zero_order_sums(sys_o, x_trj, u_trj, dx.astype(np.float64), du.astype(np.float64), sum_z=True)
+    assert dm.sums_len(SMOOTH_ZERO_ORDER_AB) == so.shape[1] == 66 + 77 + 11
+    sums = dm.smooth_accumulate(SMOOTH_ZERO_ORDER_AB, xd, ud, dev.to_dev(dx, dev.F32), dev.to_dev(du, dev.F32))
+    scale = np.abs(so).max(axis=0) + 1e-9
+    assert np.max(np.abs(sums.cpu().numpy() - so) / scale) < 2e-3          # f32 contact steps + f32 partial sums
+    At, Bt, ct, info = dm.smooth_finalize(SMOOTH_ZERO_ORDER_AB, N, xd, ud, sums)
+    Ao, Bo, co = orc.zero_order_from_sums(sys_o, x_trj, u_trj, sums.cpu().numpy())
+    assert int(info.abs().sum().item()) == 0
+    np.testing.assert_allclose(At.cpu().numpy(), Ao, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(Bt.cpu().numpy(), Bo, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(ct.cpu().numpy(), co, rtol=0, atol=1e-7)
+    fused = dm.smooth(SMOOTH_ZERO_ORDER_AB, xd, ud, dev.to_dev(dx, dev.F32), dev.to_dev(du, dev.F32))
+    np.testing.assert_allclose(fused["Bt"].cpu().numpy(), Bt.cpu().numpy(), rtol=0, atol=5e-5)
+    # ZERO_ORDER_B: two-stage == fused
+    s2 = dm.smooth_accumulate(SMOOTH_ZERO_ORDER_B, xd, ud, None, dev.to_dev(du, dev.F32))
+    assert s2.shape[1] == 10 + 28 + 4
+    A2, B2, c2, _ = dm.smooth_finalize(SMOOTH_ZERO_ORDER_B, N, xd, ud, s2)
+    f2 = dm.smooth(SMOOTH_ZERO_ORDER_B, xd, ud, None, dev.to_dev(du, dev.F32))
+    np.testing.assert_allclose(f2["Bt"].cpu().numpy(), B2.cpu().numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(f2["ct"].cpu().numpy(), c2.cpu().numpy(), rtol=0, atol=2e-5)
