@@ -223,7 +223,8 @@ def main():
             def smooth_step():
                 plan.run(stream)
                 all_reduce_sums(plan.sums)
-                tv["At"], tv["Bt"], tv["ct"], tv["info"] = dm.smooth_finalize(MODE, n_total, x_trj, u_trj, plan.sums)
+                tv["out"] = dm.smooth_finalize(MODE, n_total, x_trj, u_trj, plan.sums, out=tv.get("out"))
+                tv["At"], tv["Bt"], tv["ct"], tv["info"] = tv["out"]
 
         smooth_step()
         if w.name == "planar_hand":
@@ -242,9 +243,6 @@ def main():
             descent = dev.DescentPlan(dm, tv["At"], tv["Bt"], tv["ct"], Q, Qd, R, xd, x0)
 
             def descent_run():
-                if world > 1:       # finalize allocated fresh outputs
-                    c = descent.call
-                    c.At, c.Bt, c.ct = tv["At"].data_ptr(), tv["Bt"].data_ptr(), tv["ct"].data_ptr()
                 descent.run(stream)
 
         def ilqr_step():

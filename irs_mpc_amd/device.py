@@ -271,13 +271,17 @@ class DeviceModel:
               "irs_rng_samples")
         return dx, du
 
-    def smooth_finalize(self, mode, N_total, x_trj, u_trj, sums):
+    def smooth_finalize(self, mode, N_total, x_trj, u_trj, sums, out=None):
+        """Solve step on (all-reduced) sums -> (At, Bt, ct, info); `out` = a previous result to reuse."""
         T = u_trj.shape[0]
         dev = u_trj.device
-        At = torch.empty((T, self.n, self.n), dtype=F64, device=dev)
-        Bt = torch.empty((T, self.n, self.m), dtype=F64, device=dev)
-        ct = torch.empty((T, self.n), dtype=F64, device=dev)
-        info = torch.empty((T,), dtype=torch.int32, device=dev)
+        if out is not None:
+            At, Bt, ct, info = out
+        else:
+            At = torch.empty((T, self.n, self.n), dtype=F64, device=dev)
+            Bt = torch.empty((T, self.n, self.m), dtype=F64, device=dev)
+            ct = torch.empty((T, self.n), dtype=F64, device=dev)
+            info = torch.empty((T,), dtype=torch.int32, device=dev)
         check(self.lib.irs_smooth_finalize(self.model_id, self._p, self._np, mode, T, int(N_total),
                                            _ptr(x_trj, F64), _ptr(u_trj, F64), _ptr(sums, F64), _ptr(At, F64),
                                            _ptr(Bt, F64), _ptr(ct, F64), info.data_ptr(), _stream()),
