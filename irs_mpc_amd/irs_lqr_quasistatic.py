@@ -24,39 +24,14 @@ time step in time order -- exactly the reference's calls (quasistatic_dynamics.p
 identical seeds give identical samples -- unless `params.device_rng_seed` is set, in which case the
 perturbations are drawn on the device (Philox) and never touch the host.
 """
-import time
-
 import numpy as np
 import torch
 
 from . import device as dev
 from . import distributed as dist_util
 from ._lib import SMOOTH_ZERO_ORDER_B
+from .quasistatic_base import QuasistaticOptimizerBase, quasistatic_eval_cost  # noqa: F401
 from .tv_lqr import get_solver
-
-
-def quasistatic_eval_cost(q_dynamics, x_trj, u_trj, x_trj_d, Q_dict, Qd_dict, R):
-    """irs_lqr_quasistatic.py:153-194 (= cem_quasistatic.py:124-165): the five cost terms
-    (unactuated / actuated, running / final, input-rate), vectorised over time -- O(T n)
-    bookkeeping on trajectories already on the host."""
-    qd = q_dynamics
-    idx = qd.get_u_indices_into_x()
-    e = np.asarray(x_trj, float) - np.asarray(x_trj_d, float)
-
-    def q_cost(models, rows, Q_dict_):
-        c = 0.
-        for model in models:
-            ei = rows[..., qd.position_indices[model]]
-            c += float((ei * np.asarray(Q_dict_[model], float) * ei).sum())
-        return c
-
-    cost_Qu_final = q_cost(qd.models_unactuated, e[-1], Qd_dict)
-    cost_Qa_final = q_cost(qd.models_actuated, e[-1], Qd_dict)
-    cost_Qu = q_cost(qd.models_unactuated, e[:-1], Q_dict)
-    cost_Qa = q_cost(qd.models_actuated, e[:-1], Q_dict)
-    du = np.diff(np.vstack([np.asarray(x_trj)[0, idx][None], np.asarray(u_trj)]), axis=0)
-    cost_R = float(np.einsum("ti,ij,tj->", du, R, du))
-    return cost_Qu, cost_Qu_final, cost_Qa, cost_Qa_final, cost_R
 
 
 class IrsLqrQuasistaticParameters:
@@ -100,36 +75,11 @@ class IrsLqrQuasistaticParameters:
         self.qp_eps = 1e-9
 
 
-class IrsLqrQuasistatic:
+class IrsLqrQuasistatic(QuasistaticOptimizerBase):
     def __init__(self, q_dynamics, params):
-        self.q_dynamics = q_dynamics
-        self.dim_x = q_dynamics.dim_x
-        self.dim_u = q_dynamics.dim_u
-
-        self.params = params
-
-        self.T = params.T
-        self.x0 = params.x0
-        self.Q_dict = params.Q_dict
-        self.Q = self.q_dynamics.get_Q_from_Q_dict(self.Q_dict)
-        self.Qd_dict = params.Qd_dict
-        self.Qd = self.q_dynamics.get_Q_from_Q_dict(self.Qd_dict)
-        self.R_dict = params.R_dict
-        self.R = self.q_dynamics.get_R_from_R_dict(self.R_dict)
-        self.x_trj_d = params.x_trj_d
-        self.u_trj_0 = params.u_trj_0
-        self.x_bounds_abs = params.x_bounds_abs
-        self.u_bounds_abs = params.u_bounds_abs
-        self.x_bounds_rel = params.x_bounds_rel
-        self.u_bounds_rel = params.u_bounds_rel
-        self.indices_u_into_x = q_dynamics.get_u_indices_into_x()
-
-        self.decouple_AB = params.decouple_AB
-        self.use_workers = params.use_workers
-        self.gradient_mode = params.gradient_mode
-        self.task_stride = params.task_stride
-        self.publish_every_iteration = params.publish_every_iteration
-
+        for name in ("x_bounds_abs", "u_bounds_abs", "x_bounds_rel", "u_bounds_rel", "decouple_AB", "use_workers",
+                     "gradient_mode", "task_stride", "std_u_initial", "sampling", "num_samples"):
+            setattr(self, name, getattr(params, name))
         if self.gradient_mode != "zero_order_B" or not self.decouple_AB:
             raise NotImplementedError(
                 "gradient_mode=%r with decouple_AB=%r needs the quasistatic simulator's analytic "
@@ -138,75 +88,17 @@ class IrsLqrQuasistatic:
         if self.x_bounds_rel is not None:
             raise NotImplementedError("x_bounds_rel ('should be rarely used', irs_lqr_quasistatic.py:315) "
                                       "is not implemented on the device")
-
-        # device-resident problem data (f64)
-        self._dm = q_dynamics.dm()
+        dm = q_dynamics.dm()
         one_box = self.x_bounds_abs is None and (self.u_bounds_abs is None or self.u_bounds_rel is None)
         self._solver = int(getattr(params, "qp_solver", 0))
         if self._solver == 0:
-            self._solver = 2 if one_box and self._dm.quasistatic_descent_supported(self.T, 2) else 1
-        if not self._dm.quasistatic_descent_supported(self.T, self._solver):
-            raise NotImplementedError("horizon T=%d does not fit the LDS-resident QP factorisation" % self.T)
-        self._Q, self._Qd, self._R = (dev.to_dev(np.asarray(a, float)) for a in (self.Q, self.Qd, self.R))
-        self._x0 = dev.to_dev(np.asarray(self.x0, float))
-        self._xd = dev.to_dev(np.asarray(self.x_trj_d, float))
+            self._solver = 2 if one_box and dm.quasistatic_descent_supported(params.T, 2) else 1
+        if not dm.quasistatic_descent_supported(params.T, self._solver):
+            raise NotImplementedError("horizon T=%d does not fit the LDS-resident QP factorisation" % params.T)
+        self._setup(q_dynamics, params, params.x_trj_d)
         self._idx = torch.as_tensor(np.asarray(self.indices_u_into_x), device=self._x0.device)
-
-        self.x_trj = self.rollout(self.x0, self.u_trj_0)
-        self.u_trj = self.u_trj_0  # T x m
-
-        (cost_Qu, cost_Qu_final, cost_Qa, cost_Qa_final,
-         cost_R) = self.eval_cost(self.x_trj, self.u_trj)
-        self.cost = cost_Qu + cost_Qu_final + cost_Qa + cost_Qa_final + cost_R
-
-        self.x_trj_best = None
-        self.u_trj_best = None
-        self.cost_best = np.inf
-
-        # sampling standard deviation.
-        self.std_u_initial = params.std_u_initial
-        self.sampling = params.sampling
-        self.num_samples = params.num_samples
-
-        # logging
-        self.x_trj_list = [self.x_trj]
-        self.u_trj_list = [self.u_trj]
-
-        self.cost_all_list = [self.cost]
-        self.cost_Qu_list = [cost_Qu]
-        self.cost_Qu_final_list = [cost_Qu_final]
-        self.cost_Qa_list = [cost_Qa]
-        self.cost_Qa_final_list = [cost_Qa_final]
-        self.cost_R_list = [cost_R]
-
-        self.current_iter = 1
-        self.start_time = time.time()
-        self.verbose = True
-
-        # solver: kept for interface parity; the bounded QPs are solved on the device
+        # kept for interface parity; the bounded QPs are solved on the device
         self.solver = get_solver(params.solver_name)
-
-    # ---- irs_lqr_quasistatic.py:133-140 ---------------------------------------
-    def rollout(self, x0, u_trj):
-        T = u_trj.shape[0]
-        assert T == self.T
-        x_trj, _ = self._dm.rollout_cost(dev.to_dev(np.asarray(x0, float)), dev.to_dev(np.asarray(u_trj, float)),
-                                         self._Q, self._R, self._xd)
-        return x_trj.cpu().numpy()
-
-    # ---- irs_lqr_quasistatic.py:142-194 ---------------------------------------
-    @staticmethod
-    def calc_Q_cost(models_list, x_dict, xd_dict, Q_dict):
-        cost = 0.
-        for model in models_list:
-            dx_i = x_dict[model] - xd_dict[model]
-            cost += (dx_i * Q_dict[model] * dx_i).sum()
-        return cost
-
-    def eval_cost(self, x_trj, u_trj):
-        T = u_trj.shape[0]
-        assert T == self.T and x_trj.shape[0] == T + 1
-        return quasistatic_eval_cost(self.q_dynamics, x_trj, u_trj, self.x_trj_d, self.Q_dict, self.Qd_dict, self.R)
 
     # ---- linearisation: irs_lqr_quasistatic.py:196-273 ------------------------
     def _get_TV_matrices_dev(self, x_trj, u_trj):
@@ -298,47 +190,11 @@ class IrsLqrQuasistatic:
             # like solve_tvlqr's `raise ValueError` when the solver fails (tv_lqr.py:139-140)
             raise ValueError("TV_LQR failed. Optimization problem is not solved.")
 
-    # ---- irs_lqr_quasistatic.py:347-390 ---------------------------------------
-    def iterate(self, max_iterations):
-        x_dev = dev.to_dev(np.asarray(self.x_trj, float))
-        u_dev = dev.to_dev(np.asarray(self.u_trj, float))
-        while True:
-            if self.verbose:
-                print('Iter {:02d},'.format(self.current_iter),
-                      'cost: {:0.4f}.'.format(self.cost),
-                      'time: {:0.2f}.'.format(time.time() - self.start_time))
+    # ---- outer loop (QuasistaticOptimizerBase.iterate): the trajectory stays on the device -------
+    def _start(self):
+        return dev.to_dev(np.asarray(self.x_trj, float)), dev.to_dev(np.asarray(self.u_trj, float))
 
-            x_new_d, u_new_d, _ = self._local_descent_dev(x_dev, u_dev)
-            self._check_last()
-            x_trj_new, u_trj_new = x_new_d.cpu().numpy(), u_new_d.cpu().numpy()
-            (cost_Qu, cost_Qu_final, cost_Qa, cost_Qa_final,
-             cost_R) = self.eval_cost(x_trj_new, u_trj_new)
-            cost = cost_Qu + cost_Qu_final + cost_Qa + cost_Qa_final + cost_R
-            self.x_trj_list.append(x_trj_new)
-            self.u_trj_list.append(u_trj_new)
-            self.cost_Qu_list.append(cost_Qu)
-            self.cost_Qu_final_list.append(cost_Qu_final)
-            self.cost_Qa_list.append(cost_Qa)
-            self.cost_Qa_final_list.append(cost_Qa_final)
-            self.cost_R_list.append(cost_R)
-            self.cost_all_list.append(cost)
-
-            if self.publish_every_iteration:
-                self.q_dynamics.publish_trajectory(x_trj_new)
-
-            if self.cost_best > cost:
-                self.x_trj_best = x_trj_new
-                self.u_trj_best = u_trj_new
-                self.cost_best = cost
-
-            if self.current_iter > max_iterations:
-                break
-
-            # Go over to next iteration.
-            self.cost = cost
-            self.x_trj = x_trj_new
-            self.u_trj = u_trj_new
-            x_dev, u_dev = x_new_d, u_new_d
-            self.current_iter += 1
-
-        return self.x_trj, self.u_trj, self.cost
+    def _descend(self, state):
+        x_new_d, u_new_d, _ = self._local_descent_dev(*state)
+        self._check_last()
+        return x_new_d.cpu().numpy(), u_new_d.cpu().numpy(), (x_new_d, u_new_d)
