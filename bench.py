@@ -223,7 +223,8 @@ def main():
             def smooth_step():
                 plan.run(stream)
                 all_reduce_sums(plan.sums)
-                tv["out"] = dm.smooth_finalize(MODE, n_total, x_trj, u_trj, plan.sums, out=tv.get("out"))
+                tv["out"] = dm.smooth_finalize(MODE, n_total, x_trj, u_trj, plan.sums, out=tv.get("out"),
+                                               workspace=plan.ws)
                 tv["At"], tv["Bt"], tv["ct"], tv["info"] = tv["out"]
 
         smooth_step()

@@ -181,6 +181,15 @@ int irs_smooth_finalize(int model, const double *params, int n_params, int mode,
                         const double *sums, double *At, double *Bt, double *ct,
                         int *info, void *stream);
 
+/* irs_smooth_finalize that may reuse work of the preceding irs_smooth_accumulate[_rng] call:
+ * `workspace` = the workspace that call was given (same model, mode, T, x_trj, u_trj), or NULL.  For
+ * contact models the accumulate launch leaves f(x_t,u_t) (f64, 400 serial PGS updates each) there,
+ * evaluated by workgroup 0 of every timestep while the others sample; finalize then skips them.    */
+int irs_smooth_finalize_ws(int model, const double *params, int n_params, int mode, int T,
+                           long long N_total, const double *x_trj, const double *u_trj,
+                           const double *sums, double *At, double *Bt, double *ct, int *info,
+                           const void *workspace, size_t workspace_bytes, void *stream);
+
 /* IrsLqrExact.get_TV_matrices (irs_lqr/irs_lqr_exact.py:15-31).                  */
 int irs_exact_linearize(int model, const double *params, int n_params, int T,
                         const double *x_trj, const double *u_trj,

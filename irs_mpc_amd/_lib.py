@@ -52,6 +52,8 @@ SIGNATURES = {
                                 c_uint64, c_uint32, c_uint64, _dp, _dp, c_void_p]),
     "irs_smooth_finalize": (c_int, [c_int, POINTER(c_double), c_int, c_int, c_int, c_longlong, _dp, _dp,
                                     _dp, _dp, _dp, _dp, _dp, c_void_p]),
+    "irs_smooth_finalize_ws": (c_int, [c_int, POINTER(c_double), c_int, c_int, c_int, c_longlong, _dp, _dp,
+                                       _dp, _dp, _dp, _dp, _dp, _dp, c_size_t, c_void_p]),
     "irs_exact_linearize": (c_int, [c_int, POINTER(c_double), c_int, c_int, _dp, _dp, _dp, _dp, _dp, c_void_p]),
     "irs_tvlqr_riccati": (c_int, [c_int, c_int, c_int, _dp, _dp, _dp, _dp, _dp, _dp, c_double, _dp,
                                   _dp, _dp, _dp, c_void_p]),

@@ -394,7 +394,7 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
     // workgroup 0 owns [0, chunk0), workgroup b >= 1 owns chunk0 + [(b-1) chunk, b chunk)
     const int s_begin = blk == 0 ? 0 : a.chunk0 + (blk - 1) * a.chunk;
     const int s_end = min(a.N, blk == 0 ? a.chunk0 : a.chunk0 + blk * a.chunk);
-    constexpr bool NB = FUSE && nominal_in_wg0<Model, MODE>();
+    constexpr bool NB = nominal_in_wg0<Model, MODE>();
     if constexpr (USE_MFMA) {
         // ---- matrix-core Gram accumulation (zero-order, d <= 16, many statistics) -------
         // The P = d(d+1)/2 + d n statistics are the products Z'Z and Z'dF over the sample
@@ -552,7 +552,8 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
         block_reduce_lds<P, NW>(acc, red);
     }
     if constexpr (NB) {
-        if (blk == 0 && a.chunk0 != a.chunk && tid < 64) {
+        // (a lone fused workgroup lets its solve evaluate the step itself: same cost, no round trip)
+        if (blk == 0 && (a.nblk > 1 || !FUSE) && tid < 64) {
             double x64[n], u64[m], f64[n];
 #pragma unroll
             for (int i = 0; i < n; ++i) x64[i] = a.x_trj[(size_t)t * n + i];
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
         if (tid < 64 && a.diag != 1)
             finalize_timestep<Model, MODE>(a.p, a.x_trj, a.u_trj, tot, a.n_total, t, tid, fin, a.At, a.Bt,
                                            a.ct, a.info,
-                                           (NB && a.chunk0 != a.chunk) ? a.fnom + (size_t)t * n : nullptr);
+                                           (NB && a.nblk > 1) ? a.fnom + (size_t)t * n : nullptr);
     }
 }
 
@@ -655,8 +656,11 @@ template <class Model, int MODE>
 __global__ __launch_bounds__(64) void smooth_finalize_kernel(SmoothArgs a) {
     __shared__ FinalizeLds<Model, MODE> fin;
     const int t = blockIdx.x;
+    // a.fnom (optional): the f64 nominal steps a preceding irs_smooth_accumulate left in its workspace
+    const double* fnom = (nominal_in_wg0<Model, MODE>() && a.fnom) ? a.fnom + (size_t)t * SmoothTraits<Model, MODE>::n
+                                                                    : nullptr;
     finalize_timestep<Model, MODE>(a.p, a.x_trj, a.u_trj, a.sums + (size_t)t * SmoothTraits<Model, MODE>::P,
-                                   a.n_total, t, threadIdx.x, fin, a.At, a.Bt, a.ct, a.info);
+                                   a.n_total, t, threadIdx.x, fin, a.At, a.Bt, a.ct, a.info, fnom);
 }
 
 template <class Model>
@@ -875,7 +879,7 @@ int smooth_common(int model, const double* params, int n_params, int mode, int T
     a.T = T; a.N = N;
     plan_grid(T, N, is_light(model, mode), rng, &a.chunk, &a.nblk, &a.block);
     a.chunk0 = a.chunk;
-    if (out != nullptr && a.nblk >= 2 && a.block == kBlock && has_nominal_in_wg0(model, mode)) {
+    if (a.nblk >= 2 && a.block == kBlock && has_nominal_in_wg0(model, mode)) {
         // workgroup 0 gives up kNominalCost samples per lane and evaluates the f64 nominal step
         int c0 = a.chunk - kNominalCost * kBlock;
         if (c0 < kBlock) c0 = kBlock;
@@ -1052,7 +1056,17 @@ int irs_smooth_finalize(int model, const double* params, int n_params, int mode,
                         long long N_total, const double* x_trj, const double* u_trj,
                         const double* sums, double* At, double* Bt, double* ct, int* info,
                         void* stream) {
+    return irs_smooth_finalize_ws(model, params, n_params, mode, T, N_total, x_trj, u_trj, sums, At, Bt, ct, info,
+                                  nullptr, 0, stream);
+}
+
+int irs_smooth_finalize_ws(int model, const double* params, int n_params, int mode, int T,
+                           long long N_total, const double* x_trj, const double* u_trj,
+                           const double* sums, double* At, double* Bt, double* ct, int* info,
+                           const void* workspace, size_t workspace_bytes, void* stream) {
     IRS_CHECK_ARG(T > 0 && N_total > 0, "T and N_total must be positive");
+    IRS_CHECK_ARG(workspace == nullptr || workspace_bytes >= (size_t)kCounterBytes + fnom_bytes(T),
+                  "workspace too small to hold the nominal steps");
     IRS_CHECK_ARG(x_trj && u_trj && sums && At && Bt && ct && info, "null pointer");
     IRS_CHECK_ARG(mode >= 0 && mode <= 2, "unknown smoothing mode");
     SmoothArgs a;
@@ -1062,6 +1076,8 @@ int irs_smooth_finalize(int model, const double* params, int n_params, int mode,
     a.x_trj = x_trj; a.u_trj = u_trj; a.sums = const_cast<double*>(sums);
     a.At = At; a.Bt = Bt; a.ct = ct; a.info = info;
     a.n_total = (double)N_total; a.T = T;
+    if (workspace != nullptr)
+        a.fnom = reinterpret_cast<double*>(static_cast<char*>(const_cast<void*>(workspace)) + kCounterBytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
     IRS_DISPATCH_MODEL(model, { rc = launch_finalize<Model>(mode, a, st); });
     if (rc != IRS_OK) return rc;

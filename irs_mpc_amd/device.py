@@ -271,8 +271,10 @@ class DeviceModel:
               "irs_rng_samples")
         return dx, du
 
-    def smooth_finalize(self, mode, N_total, x_trj, u_trj, sums, out=None):
-        """Solve step on (all-reduced) sums -> (At, Bt, ct, info); `out` = a previous result to reuse."""
+    def smooth_finalize(self, mode, N_total, x_trj, u_trj, sums, out=None, workspace=None):
+        """Solve step on (all-reduced) sums -> (At, Bt, ct, info); `out` = a previous result to reuse;
+        `workspace` = the workspace tensor of the accumulate call that produced this rank's sums
+        (contact models: its f64 nominal steps are reused)."""
         T = u_trj.shape[0]
         dev = u_trj.device
         if out is not None:
@@ -282,10 +284,12 @@ class DeviceModel:
             Bt = torch.empty((T, self.n, self.m), dtype=F64, device=dev)
             ct = torch.empty((T, self.n), dtype=F64, device=dev)
             info = torch.empty((T,), dtype=torch.int32, device=dev)
-        check(self.lib.irs_smooth_finalize(self.model_id, self._p, self._np, mode, T, int(N_total),
-                                           _ptr(x_trj, F64), _ptr(u_trj, F64), _ptr(sums, F64), _ptr(At, F64),
-                                           _ptr(Bt, F64), _ptr(ct, F64), info.data_ptr(), _stream()),
-              "irs_smooth_finalize")
+        check(self.lib.irs_smooth_finalize_ws(self.model_id, self._p, self._np, mode, T, int(N_total),
+                                              _ptr(x_trj, F64), _ptr(u_trj, F64), _ptr(sums, F64), _ptr(At, F64),
+                                              _ptr(Bt, F64), _ptr(ct, F64), info.data_ptr(),
+                                              workspace.data_ptr() if workspace is not None else None,
+                                              workspace.numel() if workspace is not None else 0, _stream()),
+              "irs_smooth_finalize_ws")
         return At, Bt, ct, info
 
     def exact_linearize(self, x_trj, u_trj):

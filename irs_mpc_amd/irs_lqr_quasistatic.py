@@ -126,7 +126,9 @@ class IrsLqrQuasistatic(QuasistaticOptimizerBase):
             sums = self._dm.smooth_accumulate_rng(SMOOTH_ZERO_ORDER_B, x_trj, u_trj, hi - lo, None, std_u,
                                                   int(seed), self.current_iter, sample_offset=lo)
         dist_util.all_reduce_sums(sums)
-        At, Bt, ct, info = self._dm.smooth_finalize(SMOOTH_ZERO_ORDER_B, N, x_trj, u_trj, sums)
+        # the accumulate launch left the f64 nominal contact steps in its workspace: reuse them
+        ws = self._dm._workspace(SMOOTH_ZERO_ORDER_B, self.T, hi - lo, x_trj.device)
+        At, Bt, ct, info = self._dm.smooth_finalize(SMOOTH_ZERO_ORDER_B, N, x_trj, u_trj, sums, workspace=ws)
         self._smooth_info = info
         return At, Bt, ct
 
