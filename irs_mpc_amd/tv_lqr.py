@@ -1,11 +1,13 @@
 """Host mirror of irs_lqr/tv_lqr.py: get_solver (:11-27) and solve_tvlqr (:30-145).
 
-The reference builds a Drake MathematicalProgram and calls OSQP/Gurobi.  Here the
-equality-constrained QP is solved exactly by a backward Riccati pass on the GPU
-(irs_tvlqr_riccati) followed by the linear-model rollout of the resulting affine
-policy (irs_tvlqr_linear_rollout).  That is the QP's solution whenever no box bound
-is active; the result is checked against the bounds and an active bound raises
-(box-constrained TV-LQR is the next row of the scope table).
+The reference builds a Drake MathematicalProgram and calls OSQP/Gurobi.  This stand-alone
+function solves ONE such QP: exactly, by a backward Riccati pass on the GPU (irs_tvlqr_riccati)
+followed by the linear-model rollout of the resulting affine policy (irs_tvlqr_linear_rollout).
+That is the QP's solution whenever no box bound is active; the result is checked against the
+bounds and an active bound raises.  The reference's only callers are the MPC loops of
+`local_descent`, and those run as whole-descent kernels that DO handle active bounds and the
+position-controlled (du) cost: irs_tvlqr_box_descent (IrsLqr) and irs_quasistatic_box_descent
+(IrsLqrQuasistatic); a single bounded QP is not exposed as an entry point of its own.
 """
 import numpy as np
 
@@ -32,7 +34,8 @@ def solve_tvlqr(At, Bt, ct, Q, Qd, R, x0, x_trj_d, solver=None, indices_u_into_x
                 xinit=None, uinit=None):
     """Same signature and return value (xt_star (T+1,n), ut_star (T,m)) as tv_lqr.py:30."""
     if indices_u_into_x is not None:
-        raise NotImplementedError("delta-u cost / indices_u_into_x (tv_lqr.py:93-107) is not on device yet")
+        raise NotImplementedError("a single position-controlled QP (indices_u_into_x, tv_lqr.py:93-107) is not exposed; "
+                                  "IrsLqrQuasistatic.local_descent solves all T of them on the device")
     At_d, Bt_d, ct_d = dev.to_dev(np.asarray(At, float)), dev.to_dev(np.asarray(Bt, float)), dev.to_dev(
         np.asarray(ct, float).reshape(At.shape[0], -1))
     Q_d, Qd_d, R_d = dev.to_dev(np.asarray(Q, float)), dev.to_dev(np.asarray(Qd, float)), dev.to_dev(
@@ -57,6 +60,6 @@ def solve_tvlqr(At, Bt, ct, Q, Qd, R, x0, x_trj_d, solver=None, indices_u_into_x
     if (_active(xs, x_bound_abs, T + 1) or _active(us, u_bound_abs, T) or
             _active(np.diff(xs, axis=0), x_bound_rel, T) or
             (u_bound_rel is not None and T > 1 and _active(np.diff(us, axis=0), np.asarray(u_bound_rel)[:, 1:], T - 1))):
-        raise NotImplementedError("a box bound is active: box-constrained TV-LQR "
-                                  "(tv_lqr.py:112-123) is not implemented on device yet")
+        raise NotImplementedError("a box bound is active: a single bounded QP (tv_lqr.py:112-123) is not exposed; "
+                                  "IrsLqr.local_descent / IrsLqrQuasistatic.local_descent solve them on the device")
     return xs, us
