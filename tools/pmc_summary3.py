@@ -43,13 +43,11 @@ for d in sorted(glob.glob("%s/pmc_*" % out_dir)):
     if not os.path.isdir(d):
         continue
     ctr = os.path.basename(d)[4:]
-    f = glob.glob("%s/*/*counter_collection.csv" % d)
-    if not f:
-        continue
     vals = collections.defaultdict(list)
-    for r in csv.DictReader(open(f[0])):
-        if r.get("Counter_Name") == ctr:
-            vals[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    for fn in glob.glob("%s/*/*counter_collection.csv" % d):
+        for r in csv.DictReader(open(fn)):
+            if r.get("Counter_Name") == ctr:
+                vals[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     for name, v in vals.items():
         k = short(name)
         if k:
