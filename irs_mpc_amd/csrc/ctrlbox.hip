@@ -57,19 +57,26 @@ __device__ __forceinline__ int wave_min_i(int v) {
     return v;
 }
 
-// LDS record of one time step (doubles).  Record T holds only P, p, s.
+// LDS record of one time step (doubles).  Record T holds only P, p.
 template <int NR, int M>
 struct CbLayout {
     static constexpr int NS = NR + M;
     static constexpr int oP = 0, op = oP + NS * NS, oK = op + NS, ok = oK + M * NS, oH = ok + M,
                          oG = oH + M * M, og = oG + M * NS, oA = og + M, oB = oA + NR * NR,
-                         oc = oB + NR * M, os = oc + NR, ou = os + NS, ous = ou + M, omu = ous + M,
+                         oc = oB + NR * M, ou = oc + NR, ous = ou + M, omu = ous + M,
                          oact = omu + M, olo = oact + M, ohi = olo + M, oqsd = ohi + M, S = oqsd + NR;
     static constexpr int NTRI = NS * (NS + 1) / 2;
     static constexpr int scratch = NS * NR + 2 * M * NS + 4 * NS + 2 * M * M + M * (NS + 1) + 2 * NR * NR +
                                    NTRI + 64;
     static __host__ __device__ size_t doubles(int T) { return (size_t)(T + 1) * S + scratch; }
 };
+
+// The f64 contact step needs hundreds of registers (the 8x8 / 12x12 dual Hessian); kept out of line so
+// that its allocation does not push the solver's hot loops into scratch.  Called once per tail.
+template <class Model>
+__device__ __noinline__ void true_step(const ModelParams& p, const double* x, const double* u, double* xn) {
+    Model::template step<double>(p, x, u, xn);
+}
 
 template <class Model, int KIND>
 __global__ __launch_bounds__(64) void ctrlbox_descent_kernel(BoxArgs a) {
@@ -347,43 +354,69 @@ __global__ __launch_bounds__(64) void ctrlbox_descent_kernel(BoxArgs a) {
     };
 
     // ---- policy rollout on the linear model from sstart: controls -> record offset `dst`, mu ----
-    auto policy_rollout = [&](int t0, int dst) {
-        if (lane < NS) rec_(t0)[L::os + lane] = sstart[lane];
-        wave_sync();
-        for (int t = t0; t < T; ++t) {
-            double* rec = rec_(t);
-            const double* sv = rec + L::os;
-            if (lane < M) {
-                double s = rec[L::ok + lane];
+    // The state never leaves registers: every lane carries all of s; per step lane j < M forms
+    // control j, readlane broadcasts it, lanes M..M+NR-1 form the next x rows, readlane broadcasts
+    // them.  The coefficient rows of step t+1 are fetched from LDS while step t computes, so the
+    // dependent chain per step is two length-NS FMA chains and 2 (M + NR) readlanes -- no LDS round
+    // trip.  Outputs (controls -> record offset `dst`, multipliers -> omu) are stored off the chain.
+    auto bcast = [&](double v, int src) -> double {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+        return __hiloint2double(hi, lo);
+    };
+    struct Rows { double r1[NS], r2[NS], r3[M], c1, c2; };
+    auto load_rows = [&](int t, Rows& R) {
+        const double* rec = rec_(t);
+        const bool isu = lane < M;                       // a control lane, else an x-row lane (clamped)
+        const int i = isu ? lane : (lane - M < NR ? lane - M : 0);
 #pragma unroll
-                for (int l = 0; l < NS; ++l) s += rec[L::oK + lane * NS + l] * sv[l];
-                rec[dst + lane] = s;
-            }
-            wave_sync();
-            // s+ = [A x + B u_abs + c ; u_abs] with u_abs the absolute command (ABS: the control
-            // itself, REL: w + v) -- the same expression for both kinds
-            if (lane < M) {
-                double s = rec[L::og + lane];
-#pragma unroll
-                for (int l = 0; l < M; ++l) s += rec[L::oH + lane * M + l] * rec[dst + l];
-#pragma unroll
-                for (int l = 0; l < NS; ++l) s += rec[L::oG + lane * NS + l] * sv[l];
-                rec[L::omu + lane] = s;
-            } else if (lane < M + NR) {
-                const int i = lane - M;
-                double s = rec[L::oc + i];
-#pragma unroll
-                for (int l = 0; l < NR; ++l) s += rec[L::oA + i * NR + l] * sv[l];
-#pragma unroll
-                for (int j = 0; j < M; ++j)
-                    s += rec[L::oB + i * M + j] * (rec[dst + j] + (KIND == KIND_REL ? sv[NR + j] : 0.0));
-                rec_(t + 1)[L::os + i] = s;
-            } else if (lane < M + NS) {
-                const int j = lane - M - NR;
-                rec_(t + 1)[L::os + NR + j] = rec[dst + j] + (KIND == KIND_REL ? sv[NR + j] : 0.0);
-            }
-            wave_sync();
+        for (int l = 0; l < NS; ++l) {
+            R.r1[l] = isu ? rec[L::oK + i * NS + l] : (l < NR ? rec[L::oA + i * NR + l] : 0.0);
+            R.r2[l] = isu ? rec[L::oG + i * NS + l] : 0.0;
         }
+#pragma unroll
+        for (int l = 0; l < M; ++l) R.r3[l] = isu ? rec[L::oH + i * M + l] : rec[L::oB + i * M + l];
+        R.c1 = isu ? rec[L::ok + i] : rec[L::oc + i];
+        R.c2 = isu ? rec[L::og + i] : 0.0;
+    };
+    auto policy_rollout = [&](int t0, int dst) {
+        double sr[NS];
+#pragma unroll
+        for (int l = 0; l < NS; ++l) sr[l] = sstart[l];
+        Rows cur, nxt;
+        load_rows(t0, cur);
+        for (int t = t0; t < T; ++t) {
+            if (t + 1 < T) load_rows(t + 1, nxt);
+            // controls (lanes < M), then broadcast
+            double acc = cur.c1;
+#pragma unroll
+            for (int l = 0; l < NS; ++l) acc += cur.r1[l] * sr[l];      // control lane: K_j s + k_j; x lane: A_i x + c_i
+            double v[M];
+#pragma unroll
+            for (int j = 0; j < M; ++j) v[j] = bcast(acc, j);
+            double ua[M];                                                // absolute command
+#pragma unroll
+            for (int j = 0; j < M; ++j) ua[j] = v[j] + (KIND == KIND_REL ? sr[NR + j] : 0.0);
+            // multipliers (control lanes, off the chain) and next x rows (x lanes)
+            double tail = 0.0;
+#pragma unroll
+            for (int l = 0; l < M; ++l) tail += cur.r3[l] * (lane < M ? v[l] : ua[l]);   // H_j v  |  B_i u_abs
+            if (lane < M) {
+                double mu = cur.c2 + tail;
+#pragma unroll
+                for (int l = 0; l < NS; ++l) mu += cur.r2[l] * sr[l];
+                double* rec = rec_(t);
+                rec[dst + lane] = acc;
+                rec[L::omu + lane] = mu;
+            }
+            const double xrow = acc + tail;                              // meaningful on lanes M..M+NR-1
+#pragma unroll
+            for (int i = 0; i < NR; ++i) sr[i] = bcast(xrow, M + i);
+#pragma unroll
+            for (int j = 0; j < M; ++j) sr[NR + j] = ua[j];
+            cur = nxt;
+        }
+        wave_sync();
     };
 
     // ---- MPC loop --------------------------------------------------------------------
@@ -552,7 +585,7 @@ __global__ __launch_bounds__(64) void ctrlbox_descent_kernel(BoxArgs a) {
             for (int j = 0; j < M; ++j) dv[j] = ur[j] - (tau == 0 ? ub[j] : up[j]);
             cost += quad(Qsym, e, NR) + quad(Rsym, dv, M);
         }
-        Model::template step<double>(a.p, xr, ur, xn);
+        true_step<Model>(a.p, xr, ur, xn);
 #pragma unroll
         for (int i = 0; i < NR; ++i) xr[i] = xn[i];
 #pragma unroll

@@ -1,5 +1,6 @@
 """Times the quasistatic (du-cost, trust-region) descent of the planar hand at BASELINE's horizon:
-active-set solver vs ADMM, u_bounds_abs vs u_bounds_rel.   python tools/time_quasistatic.py [T] [N]"""
+active-set solver (and ADMM with --admm: seconds per descent), u_bounds_abs vs u_bounds_rel.
+    python tools/time_quasistatic.py [T] [N] [--admm]"""
 import os
 import sys
 import time
@@ -10,8 +11,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from irs_mpc_amd import PlanarHandDynamics, device as dev, _lib  # noqa: E402
 
-T = int(sys.argv[1]) if len(sys.argv) > 1 else 50
-N = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+args = [v for v in sys.argv[1:] if not v.startswith("--")]
+T = int(args[0]) if len(args) > 0 else 50
+N = int(args[1]) if len(args) > 1 else 10000
 sysd = PlanarHandDynamics(0.1)
 dm = sysd.dm()
 parts = lambda obj, arm_l, arm_r: sysd.get_x_from_q_dict({"sphere": obj, "arm_left": arm_l, "arm_right": arm_r})
@@ -34,7 +36,7 @@ cases = {"abs": dict(u_lo=(nom - 0.05).contiguous(), u_hi=(nom + 0.05).contiguou
                      du_hi=torch.full((T, 4), 0.03, dtype=torch.float64, device="cuda")),
          "none": dict()}
 for name, b in cases.items():
-    for solver, label in ((2, "active-set"), (1, "ADMM")):
+    for solver, label in ((2, "active-set"),) + (((1, "ADMM"),) if "--admm" in sys.argv else ()):
         kw = dict(solver=solver, rho=100.0, relax=1.6, max_iter=20000 if solver == 1 else 2000, eps=1e-9)
         out = dm.quasistatic_box_descent(At, Bt, ct, Q, Qd, R, xd, x0d, **b, **kw)
         torch.cuda.synchronize()
