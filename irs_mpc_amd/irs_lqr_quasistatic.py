@@ -16,7 +16,8 @@ underneath:
     (csrc/boxqp.hip, ADMM around a shared Riccati factorisation of the [x; u_prev] problem).
   * `q_dynamics` is a device-backed functor (e.g. PlanarHandDynamics), not the external
     quasistatic_simulator; gradient modes that need the simulator's analytic derivatives
-    ("first_order", "exact", and "zero_order_B" without decouple_AB) raise NotImplementedError.
+    ("first_order", "exact", and any mode without decouple_AB) raise NotImplementedError;
+    "zero_order_B" and "zero_order_AB" (the damped joint fit of calc_AB_zero_order) run.
 
 `params.sampling(std_u_initial, iter)` returns the std of the u-perturbations like the reference;
 the draws are made on the host by `np.random.normal(0, std_u, (num_samples, dim_u))` once per
@@ -29,7 +30,7 @@ import torch
 
 from . import device as dev
 from . import distributed as dist_util
-from ._lib import SMOOTH_ZERO_ORDER_B
+from ._lib import SMOOTH_ZERO_ORDER_AB, SMOOTH_ZERO_ORDER_B
 from .quasistatic_base import QuasistaticOptimizerBase, quasistatic_eval_cost  # noqa: F401
 from .tv_lqr import get_solver
 
@@ -80,11 +81,11 @@ class IrsLqrQuasistatic(QuasistaticOptimizerBase):
         for name in ("x_bounds_abs", "u_bounds_abs", "x_bounds_rel", "u_bounds_rel", "decouple_AB", "use_workers",
                      "gradient_mode", "task_stride", "std_u_initial", "sampling", "num_samples"):
             setattr(self, name, getattr(params, name))
-        if self.gradient_mode != "zero_order_B" or not self.decouple_AB:
+        if self.gradient_mode not in ("zero_order_B", "zero_order_AB") or not self.decouple_AB:
             raise NotImplementedError(
                 "gradient_mode=%r with decouple_AB=%r needs the quasistatic simulator's analytic "
-                "derivatives (q_sim.get_Dq_nextDq); the device functors provide zero_order_B with "
-                "decouple_AB=True" % (self.gradient_mode, self.decouple_AB))
+                "derivatives (q_sim.get_Dq_nextDq); the device functors provide zero_order_B and "
+                "zero_order_AB with decouple_AB=True" % (self.gradient_mode, self.decouple_AB))
         if self.x_bounds_rel is not None:
             raise NotImplementedError("x_bounds_rel ('should be rarely used', irs_lqr_quasistatic.py:315) "
                                       "is not implemented on the device")
@@ -104,6 +105,8 @@ class IrsLqrQuasistatic(QuasistaticOptimizerBase):
     def _get_TV_matrices_dev(self, x_trj, u_trj):
         std_u = np.broadcast_to(np.asarray(self.sampling(self.std_u_initial, self.current_iter), float),
                                 (self.dim_u,))
+        if self.gradient_mode == "zero_order_AB":
+            return self._zero_order_AB_dev(x_trj, u_trj, std_u)
         rank, world = dist_util.rank_world()
         N = self.num_samples
         seed = getattr(self.params, "device_rng_seed", None)
@@ -131,6 +134,49 @@ class IrsLqrQuasistatic(QuasistaticOptimizerBase):
         At, Bt, ct, info = self._dm.smooth_finalize(SMOOTH_ZERO_ORDER_B, N, x_trj, u_trj, sums, workspace=ws)
         self._smooth_info = info
         return At, Bt, ct
+
+    # calc_AB_zero_order's defaults (quasistatic_dynamics.py:268-272)
+    ZERO_ORDER_AB_STD_X = 1e-3
+    ZERO_ORDER_AB_DAMP = 1e-2
+
+    def _zero_order_AB_dev(self, x_trj, u_trj, std_u):
+        """gradient_mode "zero_order_AB" (quasistatic_dynamics.py:268-300): x AND u are perturbed
+        (dx ~ N(0, 1e-3), drawn first, as there), and `damp`-weighted identity rows regularise the
+        least squares.  Those rows add damp^2 to the Gram diagonal and nothing to the cross term, so
+        the path is: accumulate the statistics, add damp^2 on the diagonal entries of the (all-reduced)
+        sums, solve; then decouple_AB_matrices (:275-284) and c_t = f - A x - B u with the decoupled
+        pair, f recovered from the undecoupled solve."""
+        rank, world = dist_util.rank_world()
+        N, n, m, T = self.num_samples, self.dim_x, self.dim_u, self.T
+        lo, hi = dist_util.shard_range(N, rank, world)
+        seed = getattr(self.params, "device_rng_seed", None)
+        if seed is None:
+            dx, du = [], []
+            for _ in range(T):
+                dx.append(np.random.normal(0, self.ZERO_ORDER_AB_STD_X, size=[N, n]))
+                du.append(np.random.normal(0, std_u, size=[N, m]))
+            dxd = dev.to_dev(np.ascontiguousarray(np.stack(dx)[:, lo:hi], np.float32), dev.F32)
+            dud = dev.to_dev(np.ascontiguousarray(np.stack(du)[:, lo:hi], np.float32), dev.F32)
+            sums = self._dm.smooth_accumulate(SMOOTH_ZERO_ORDER_AB, x_trj, u_trj, dxd, dud)
+        else:
+            sums = self._dm.smooth_accumulate_rng(SMOOTH_ZERO_ORDER_AB, x_trj, u_trj, hi - lo,
+                                                  np.full(n, self.ZERO_ORDER_AB_STD_X), std_u, int(seed),
+                                                  self.current_iter, sample_offset=lo)
+        dist_util.all_reduce_sums(sums)
+        d = n + m
+        diag = torch.as_tensor([i * d - i * (i - 1) // 2 for i in range(d)], device=sums.device)
+        sums[:, diag] += self.ZERO_ORDER_AB_DAMP ** 2
+        ws = self._dm._workspace(SMOOTH_ZERO_ORDER_AB, T, hi - lo, x_trj.device)
+        At, Bt, ct, info = self._dm.smooth_finalize(SMOOTH_ZERO_ORDER_AB, N, x_trj, u_trj, sums, workspace=ws)
+        self._smooth_info = info
+        # f = c + A x + B u with the fitted pair; then overwrite the structure and rebuild c
+        f = ct + torch.einsum("tij,tj->ti", At, x_trj[:-1]) + torch.einsum("tij,tj->ti", Bt, u_trj)
+        eye_m = torch.eye(m, dtype=At.dtype, device=At.device)
+        Bt[:, self._idx, :] = eye_m
+        At[:] = torch.eye(n, dtype=At.dtype, device=At.device)
+        At[:, :, self._idx] = 0.0
+        ct = f - torch.einsum("tij,tj->ti", At, x_trj[:-1]) - torch.einsum("tij,tj->ti", Bt, u_trj)
+        return At, Bt, ct.contiguous()
 
     def get_TV_matrices(self, x_trj, u_trj):
         T = u_trj.shape[0]

@@ -607,6 +607,28 @@ def zero_order_B_fit(du, dx_next):
     return np.linalg.lstsq(du, dx_next, rcond=None)[0].transpose()
 
 
+def zero_order_AB_damped_decoupled(system, x_trj, u_trj, dx, du, damp=1e-2):
+    """calc_AB_zero_order (irs_lqr/quasistatic_dynamics.py:268-300): least squares of the one-step
+    responses on [dx | du] with `damp`-weighted identity rows appended (Tikhonov), followed by
+    decouple_AB_matrices (irs_lqr_quasistatic.py:275-284) and c = f - A x - B u."""
+    T, n, m = u_trj.shape[0], system.dim_x, system.dim_u
+    d = n + m
+    idx = system.indices_u_into_x
+    At, Bt, ct = np.zeros((T, n, n)), np.zeros((T, n, m)), np.zeros((T, n))
+    for t in range(T):
+        ft = system.dynamics(x_trj[t], u_trj[t])
+        dfn = system.dynamics_batch(x_trj[t] + dx[t], u_trj[t] + du[t]) - ft
+        lhs = np.vstack([np.hstack([dx[t], du[t]]), damp * np.eye(d)])
+        rhs = np.vstack([dfn, np.zeros((d, n))])
+        AB = np.linalg.lstsq(lhs, rhs, rcond=None)[0].T
+        Bt[t] = AB[:, n:]
+        Bt[t][idx, :] = np.eye(m)
+        At[t] = np.eye(n)
+        At[t][:, idx] = 0.0
+        ct[t] = ft - At[t].dot(x_trj[t]) - Bt[t].dot(u_trj[t])
+    return At, Bt, ct
+
+
 def gaussian_samples(T, N, std_x, std_u, it, power=0.5):
     """The sampling closure of the example scripts, e.g.
     examples/pendulum/pendulum_zero_order.py:38-43: per t, dx~N(0,std_x/iter^p)

@@ -1121,3 +1121,42 @@ def test_contact_model_sums_layout_vs_oracle(amd):
     f2 = dm.smooth(SMOOTH_ZERO_ORDER_B, xd, ud, None, dev.to_dev(du, dev.F32))
     np.testing.assert_allclose(f2["Bt"].cpu().numpy(), B2.cpu().numpy(), rtol=0, atol=2e-5)
     np.testing.assert_allclose(f2["ct"].cpu().numpy(), c2.cpu().numpy(), rtol=0, atol=2e-5)
+
+
+def test_irs_lqr_quasistatic_zero_order_AB_mode(amd):
+    """gradient_mode "zero_order_AB" (quasistatic_dynamics.py:268-300: x and u noise, damped least
+    squares) + decouple_AB through the host twin == the oracle on identical np.random seeds."""
+    T, N = 6, 1500
+    sys_d, sys_o, x0, u_trj, _, _, _, (Q, Qd, R, xd) = _hand_problem(amd, T, 4, 0)
+    p = amd.IrsLqrQuasistaticParameters()
+    q_dict = {"sphere": np.array([1e-3, 1e-3, 10.0]), "arm_left": np.array([1e-3, 1e-3]),
+              "arm_right": np.array([1e-3, 1e-3])}
+    p.Q_dict, p.Qd_dict = q_dict, {k: 100 * v for k, v in q_dict.items()}
+    p.R_dict = {"arm_left": 5 * np.ones(2), "arm_right": 5 * np.ones(2)}
+    p.x0, p.x_trj_d, p.u_trj_0, p.T = x0, xd, u_trj, T
+    p.u_bounds_abs = np.array([-np.ones(4) * 0.05, np.ones(4) * 0.05])
+    p.sampling = lambda u_initial, it: u_initial / (it ** 0.8)
+    p.std_u_initial, p.num_samples = np.ones(4) * 0.1, N
+    p.gradient_mode = "zero_order_AB"
+    p.publish_every_iteration = False
+    sol = amd.IrsLqrQuasistatic(sys_d, p)
+    sol.verbose = False
+    np.random.seed(11)
+    At, Bt, ct = sol.get_TV_matrices(sol.x_trj, sol.u_trj)
+    np.random.seed(11)
+    dx, du = [], []
+    for _ in range(T):
+        dx.append(np.random.normal(0, 1e-3, size=[N, 7]))
+        du.append(np.random.normal(0, p.std_u_initial, size=[N, 4]))
+    dx, du = np.stack(dx).astype(np.float32).astype(np.float64), np.stack(du).astype(np.float32).astype(np.float64)
+    Ao, Bo, co = orc.zero_order_AB_damped_decoupled(sys_o, sol.x_trj, sol.u_trj, dx, du)
+    np.testing.assert_allclose(At, Ao, rtol=0, atol=0)
+    np.testing.assert_allclose(Bt, Bo, rtol=0, atol=5e-4)          # f32 contact steps
+    np.testing.assert_allclose(ct, co, rtol=0, atol=5e-4)
+    c0 = sol.cost
+    sol.iterate(2)
+    assert sol.cost_best < c0
+    # the simulator-derivative modes stay refused
+    p.gradient_mode = "first_order"
+    with pytest.raises(NotImplementedError):
+        amd.IrsLqrQuasistatic(sys_d, p)
