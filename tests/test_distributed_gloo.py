@@ -12,7 +12,20 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, T, N, out_dir):
+def _problem(name, T):
+    """(oracle system, nominal x, u, perturbation scales, contact-model sums layout?)"""
+    from oracle import irs_oracle as orc
+    if name == "pendulum":
+        s = orc.PendulumOracle(0.05)
+        u = np.tile(np.array([0.1]), (T, 1))
+        return s, orc.rollout(s, np.zeros(2), u), u, 1.0, 1.0, False
+    s = orc.PlanarHandOracle(0.1, pgs_iters=20)
+    x0 = orc.PlanarHandOracle.pack([0.0, 0.35, 0.0], [-np.pi / 4, -np.pi / 4], [np.pi / 4, np.pi / 4])
+    u = np.tile(x0[s.indices_u_into_x], (T, 1))
+    return s, orc.rollout(s, x0, u), u, 0.01, 0.1, True        # contact models ship [Gram | z(f-xb)' | sum z]
+
+
+def _worker(rank, world, port, T, N, out_dir, name="pendulum"):
     sys.path.insert(0, ROOT)
     import torch
     from oracle import irs_oracle as orc
@@ -21,13 +34,11 @@ def _worker(rank, world, port, T, N, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     assert rank_world() == (rank, world)
-    s = orc.PendulumOracle(0.05)
-    u = np.tile(np.array([0.1]), (T, 1))
-    x = orc.rollout(s, np.zeros(2), u)
+    s, x, u, sx, su, sum_z = _problem(name, T)
     rng = np.random.default_rng(0)              # every rank draws the same full set
-    dx, du = rng.normal(size=(T, N, 2)), rng.normal(size=(T, N, 1))
+    dx, du = sx * rng.normal(size=(T, N, s.dim_x)), su * rng.normal(size=(T, N, s.dim_u))
     lo, hi = shard_range(N, rank, world)
-    sums = torch.from_numpy(orc.zero_order_sums(s, x, u, dx[:, lo:hi], du[:, lo:hi]))
+    sums = torch.from_numpy(orc.zero_order_sums(s, x, u, dx[:, lo:hi], du[:, lo:hi], sum_z=sum_z))
     all_reduce_sums(sums)
     At, Bt, ct = orc.zero_order_from_sums(s, x, u, sums.numpy())
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), At=At, Bt=Bt, ct=ct, lo=lo, hi=hi)
@@ -53,6 +64,26 @@ def test_two_rank_sharded_smoothing_equals_unsharded(tmp_path):
     np.testing.assert_allclose(r0["At"], At, rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(r0["Bt"], Bt, rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(r0["ct"], ct, rtol=1e-9, atol=1e-11)
+
+
+def test_two_rank_sharded_smoothing_contact_model_layout(tmp_path):
+    """The same for a contact model, whose statistics carry sum(z) and are measured from the nominal
+    STATE (include/irs_hip.h): shards add, and the solve's nominal-step correction recovers the
+    unsharded least squares."""
+    from oracle import irs_oracle as orc
+    T, N, world = 3, 301, 2
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(world, port, T, N, str(tmp_path), "planar_hand"), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    for k in ("At", "Bt", "ct"):
+        assert np.array_equal(r0[k], r1[k])
+    s, x, u, sx, su, _ = _problem("planar_hand", T)
+    rng = np.random.default_rng(0)
+    dx, du = sx * rng.normal(size=(T, N, 7)), su * rng.normal(size=(T, N, 4))
+    At, Bt, ct = orc.zero_order_TV(s, x, u, dx, du)
+    np.testing.assert_allclose(r0["At"], At, rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(r0["Bt"], Bt, rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(r0["ct"], ct, rtol=1e-7, atol=1e-8)
 
 
 def test_shard_range_partitions():
