@@ -409,3 +409,69 @@ def test_box_pivot_oracle_physics():
     x = orc.BoxPivotOracle.pack([0.0, 3.0, 0.3], [-2.0, 1.0])
     xn = o.dynamics(x, np.array([-1.9, 1.1]))
     np.testing.assert_allclose(xn[o.PERM], [0.0, 3.0 - 9.81 * 0.01, 0.3, -1.9, 1.1], atol=1e-12)
+
+
+@pytest.mark.parametrize("kind", ["abs", "rel"])
+def test_ctrlbox_active_set_equals_admm_on_random_problems(kind):
+    """The active-set solver's oracle twin (ctrlbox_solve: primal-dual active set + primal safeguard on
+    the control-box form) against the ADMM solution of the SAME QP posed on the [x; u_prev]
+    augmentation -- two independent algorithms, random dynamics / costs / bounds."""
+    rng = np.random.default_rng(7 if kind == "abs" else 8)
+    worst, used_fallback = 0.0, 0
+    for _ in range(8):
+        n, m, T = int(rng.integers(2, 6)), int(rng.integers(1, 4)), int(rng.integers(5, 13))
+        At = np.eye(n) + 0.2 * rng.normal(size=(T, n, n))
+        Bt, ct = rng.normal(size=(T, n, m)), 0.1 * rng.normal(size=(T, n))
+        Q = np.diag(rng.uniform(0.01, 5, n))
+        Qd, R = 10 * Q, np.diag(rng.uniform(0.1, 5, m))
+        xd, x0, w0 = rng.normal(size=(T + 1, n)), rng.normal(size=n), 0.1 * rng.normal(size=m)
+        width, centre = rng.uniform(0.02, 0.5), 0.1 * rng.normal(size=(T, m))
+        lo, hi = centre - width, centre + width
+        prob = orc.quasistatic_ctrl_problem(At, Bt, ct, Q, Qd, R, xd, kind)
+        W, act, u = orc.ctrlbox_workspace(prob), np.zeros((T, m), dtype=int), np.zeros((T, m))
+        s0 = np.concatenate([x0, w0])
+        _, u, _, st, _ = orc.ctrlbox_solve(prob, s0, 0, lo, hi, u, act, W, T)
+        assert st[1] >= 0                                        # converged
+        used_fallback += st[1] > 0
+        Ab, Bb, cb, Qb, Qdb, xdb = orc.quasistatic_augment(At, Bt, ct, Q, Qd, xd)
+        inf = np.inf
+        if kind == "rel":
+            zlo, zhi, vlo, vhi = np.full((T + 1, n + m), -inf), np.full((T + 1, n + m), inf), lo, hi
+        else:
+            zlo = np.hstack([np.full((T + 1, n), -inf), np.vstack([np.full((1, m), -inf), lo])])
+            zhi = np.hstack([np.full((T + 1, n), inf), np.vstack([np.full((1, m), inf), hi])])
+            vlo, vhi = np.full((T, m), -inf), np.full((T, m), inf)
+        F = orc.tvlqr_box_factor(Ab, Bb, cb, Qb, Qdb, R, zlo, zhi, vlo, vhi, 10.0, alpha_R=1.0)
+        zx, _, _, it = orc.tvlqr_box_solve(F, Ab, Bb, cb, Qb, Qdb, xdb, s0, 0, zlo, zhi, vlo, vhi, None, 100000,
+                                           1e-11, 1.6)
+        assert it < 100000
+        u_abs = u if kind == "abs" else s0[n:] + np.cumsum(u, axis=0)
+        worst = max(worst, np.abs(zx[1:, n:] - u_abs).max())
+    assert worst < 1e-8
+
+
+def test_quasistatic_descent_two_solvers_agree():
+    """local_descent_quasistatic (ADMM) == local_descent_quasistatic_as (active set) on the planar hand,
+    trust-region and rate-limit bounds: the whole MPC loop with the contact step in it."""
+    T = 8
+    o = orc.PlanarHandOracle(0.1)
+    x0 = _hand_x0()
+    for _ in range(4):
+        x0 = o.dynamics(x0, _hand_x0()[o.indices_u_into_x])
+    idx = o.indices_u_into_x
+    u_trj = np.tile(x0[idx], (T, 1))
+    x_trj = orc.rollout(o, x0, u_trj)
+    At, Bt, ct = orc.zero_order_B_decoupled(o, x_trj, u_trj, 0.1 * np.random.default_rng(2).normal(size=(T, 300, 4)))
+    q = orc.PlanarHandOracle.pack([1e-3, 1e-3, 10], [1e-3, 1e-3], [1e-3, 1e-3])
+    Q, Qd, R = np.diag(q), np.diag(100 * q), 5 * np.eye(4)
+    xd = np.tile(x0 + orc.PlanarHandOracle.pack([0.3, -0.1, 0.5], [0, 0], [0, 0]), (T + 1, 1))
+    for kind, ub, rb in (("abs", np.array([-np.ones(4) * 0.05, np.ones(4) * 0.05]), None),
+                         ("rel", None, np.array([-np.ones(4) * 0.03, np.ones(4) * 0.03]))):
+        rows = orc.quasistatic_bounds(x_trj, idx, None, ub, rb)
+        lo, hi = (rows[2], rows[3]) if kind == "abs" else (rows[4], rows[5])
+        xa, ua, stats = orc.local_descent_quasistatic_as(o, At, Bt, ct, Q, Qd, R, x0, xd, lo, hi, kind)
+        xb, ub_, iters = orc.local_descent_quasistatic(o, At, Bt, ct, Q, Qd, R, x0, xd, *rows, rho=100.0,
+                                                       max_iter=40000, eps=1e-11, relax=1.6)
+        assert max(iters) < 40000 and all(st[1] >= 0 for st in stats)
+        np.testing.assert_allclose(ua, ub_, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(xa, xb, rtol=0, atol=1e-8)
