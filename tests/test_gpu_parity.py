@@ -1160,3 +1160,56 @@ def test_irs_lqr_quasistatic_zero_order_AB_mode(amd):
     p.gradient_mode = "first_order"
     with pytest.raises(NotImplementedError):
         amd.IrsLqrQuasistatic(sys_d, p)
+
+
+def test_planar_hand_full_size_properties(amd):
+    """BASELINE configs[3] at its per-GPU size (planar_hand, T=50, N=10^5), through properties that do
+    not need the oracle at that size: 8 logical shards add up to the unsharded statistics; the solve
+    of the summed shards equals the fused single launch; launches are bit-reproducible; the decoupled
+    structure is exact; the device-RNG stream does not depend on the split; and a 1 % subsample of the
+    estimate agrees with the NumPy oracle on the same samples."""
+    from irs_mpc_amd import device as dev
+    from irs_mpc_amd._lib import SMOOTH_ZERO_ORDER_B
+    from irs_mpc_amd.distributed import shard_range
+    T, N = 50, 100000
+    sys_d, sys_o, x0, _ = _hand_setup(amd, T)
+    u_np = np.tile(x0[HAND_IDX], (T, 1))
+    x_np = orc.rollout(sys_o, x0, u_np)
+    x_trj, u_trj = dev.to_dev(x_np), dev.to_dev(u_np)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    du = 0.3 * torch.randn((T, N, 4), generator=g, device="cuda", dtype=torch.float32)
+    dm = sys_d.dm()
+    full = dm.smooth_accumulate(SMOOTH_ZERO_ORDER_B, x_trj, u_trj, None, du).clone()
+    acc = torch.zeros_like(full)
+    for r in range(8):
+        lo, hi = shard_range(N, r, 8)
+        acc += dm.smooth_accumulate(SMOOTH_ZERO_ORDER_B, x_trj, u_trj, None, du[:, lo:hi].contiguous())
+    scale = full.abs().max(dim=0).values + 1e-12
+    assert float(((acc - full).abs() / scale).max()) < 2e-5
+    A1, B1, c1, i1 = dm.smooth_finalize(SMOOTH_ZERO_ORDER_B, N, x_trj, u_trj, acc)
+    fused = dm.smooth(SMOOTH_ZERO_ORDER_B, x_trj, u_trj, None, du)
+    assert int(i1.abs().sum().item()) == 0 and int(fused["info"].abs().sum().item()) == 0
+    np.testing.assert_allclose(B1.cpu().numpy(), fused["Bt"].cpu().numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(c1.cpu().numpy(), fused["ct"].cpu().numpy(), rtol=0, atol=2e-5)
+    B_first = fused["Bt"].clone()
+    again = dm.smooth(SMOOTH_ZERO_ORDER_B, x_trj, u_trj, None, du)
+    assert torch.equal(again["Bt"], B_first) and torch.equal(again["sums"], fused["sums"])
+    # decouple_AB structure, exactly (irs_lqr_quasistatic.py:275-284)
+    A_exp = np.eye(7)
+    A_exp[:, HAND_IDX] = 0.0
+    assert np.array_equal(fused["At"].cpu().numpy(), np.tile(A_exp, (T, 1, 1)))
+    assert np.array_equal(fused["Bt"].cpu().numpy()[:, HAND_IDX, :], np.tile(np.eye(4), (T, 1, 1)))
+    # device RNG: a pure function of the global sample index
+    std_u = 0.3 * np.ones(4)
+    s_all = dm.smooth_accumulate_rng(SMOOTH_ZERO_ORDER_B, x_trj, u_trj, N, None, std_u, 99, 2).clone()
+    s_two = dm.smooth_accumulate_rng(SMOOTH_ZERO_ORDER_B, x_trj, u_trj, 60000, None, std_u, 99, 2).clone()
+    s_two += dm.smooth_accumulate_rng(SMOOTH_ZERO_ORDER_B, x_trj, u_trj, 40000, None, std_u, 99, 2, sample_offset=60000)
+    assert float(((s_two - s_all).abs() / (s_all.abs().max(dim=0).values + 1e-12)).max()) < 2e-5
+    # a 1 % subsample against the oracle (three time steps)
+    sub = du[:, :1000].contiguous()
+    o_sub = dm.smooth(SMOOTH_ZERO_ORDER_B, x_trj, u_trj, None, sub)
+    for t in (0, 17, 49):
+        fn = sys_o.dynamics_batch(np.tile(x_np[t], (1000, 1)), u_np[t] + sub[t].cpu().numpy().astype(np.float64))
+        Bo = orc.zero_order_B_fit(sub[t].cpu().numpy().astype(np.float64), fn - sys_o.dynamics(x_np[t], u_np[t]))
+        Bo[HAND_IDX, :] = np.eye(4)
+        np.testing.assert_allclose(o_sub["Bt"][t].cpu().numpy(), Bo, rtol=0, atol=5e-4)
