@@ -15,8 +15,9 @@ void irs_set_error(const char* fmt, ...) {
 
 namespace {
 
+// 64-thread workgroups: a contact step holds hundreds of f64 registers per lane (no spills at 512)
 template <class Model>
-__global__ void dynamics_batch_kernel(ModelParams p, const double* X, const double* U, int B, double* Xn) {
+__global__ __launch_bounds__(64) void dynamics_batch_kernel(ModelParams p, const double* X, const double* U, int B, double* Xn) {
     constexpr int n = Model::NX, m = Model::NU;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -71,7 +72,7 @@ int irs_dynamics_batch(int model, const double* params, int n_params, const doub
     if (rc != IRS_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     IRS_DISPATCH_MODEL(model, {
-        hipLaunchKernelGGL((dynamics_batch_kernel<Model>), dim3((B + 255) / 256), dim3(256), 0, st, p, X, U, B, Xn);
+        hipLaunchKernelGGL((dynamics_batch_kernel<Model>), dim3((B + 63) / 64), dim3(64), 0, st, p, X, U, B, Xn);
     });
     IRS_CHECK_LAUNCH();
     return IRS_OK;
