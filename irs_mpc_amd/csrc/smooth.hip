@@ -734,7 +734,7 @@ constexpr int kBigBlock = 1024;
 //  * otherwise 256-thread workgroups, ~tune_spt() samples per lane, at least enough
 //    workgroups to cover the CUs (while each lane still has >= 4 samples) and at most
 //    ~4 per CU (light kernels) or 1 per CU (kernels that hold 1 wave per SIMD).
-void plan_grid(int T, int N, bool light, bool rng, int* chunk, int* nblk, int* block) {
+void plan_grid(int T, int N, bool light, bool rng, int* chunk, int* nblk, int* block, bool contact = false) {
     if (light && !rng && N <= tune_single_max()) {
         *block = kBigBlock;
         *nblk = 1;
@@ -749,8 +749,11 @@ void plan_grid(int T, int N, bool light, bool rng, int* chunk, int* nblk, int* b
     int by4 = (N + kBlock * 4 - 1) / (kBlock * 4);        // ... keeping >= 4 samples per lane
     if (fill > by4) fill = by4;
     if (nb < fill) nb = fill;
-    // heavy kernels: 1 workgroup per CU, 2 once there is enough work to hide the tail
-    const int heavy_cap = tune_max_wg_heavy() * ((long long)N * T >= 2000000 ? 2 : 1);
+    // heavy kernels: 1 workgroup per CU, 2 once there is enough work to hide the tail.  Contact
+    // kernels (one VALU-saturating wave per SIMD) switch later: at T = 50 two workgroups per CU lose
+    // 35 % at N = 4e4, 13 % at 6e4, and win 7 % from N = 1e5 on (measured, profiles/).
+    const long long two_per_cu = contact ? 5000000 : 2000000;
+    const int heavy_cap = tune_max_wg_heavy() * ((long long)N * T >= two_per_cu ? 2 : 1);
     int max_blk = (light ? tune_max_wg() : heavy_cap) / T;
     if (max_blk < 1) max_blk = 1;
     if (nb > max_blk) nb = max_blk;
@@ -877,7 +880,7 @@ int smooth_common(int model, const double* params, int n_params, int mode, int T
     }
     a.x_trj = x_trj; a.u_trj = u_trj;
     a.T = T; a.N = N;
-    plan_grid(T, N, is_light(model, mode), rng, &a.chunk, &a.nblk, &a.block);
+    plan_grid(T, N, is_light(model, mode), rng, &a.chunk, &a.nblk, &a.block, has_nominal_in_wg0(model, mode));
     a.chunk0 = a.chunk;
     if (a.nblk >= 2 && a.block == kBlock && has_nominal_in_wg0(model, mode)) {
         // workgroup 0 gives up kNominalCost samples per lane and evaluates the f64 nominal step
@@ -949,7 +952,8 @@ size_t irs_smooth_workspace_bytes(int model, int mode, int T, int N) {
     int P = irs_sums_len(model, mode);
     if (P <= 0 || T <= 0 || N <= 0) return 0;
     int chunk, nblk, block;
-    plan_grid(T, N, is_light(model, mode), /*rng=*/true, &chunk, &nblk, &block);   // the larger grid
+    plan_grid(T, N, is_light(model, mode), /*rng=*/true, &chunk, &nblk, &block,       // the larger grid
+              has_nominal_in_wg0(model, mode));
     return kCounterBytes + fnom_bytes(T) + (size_t)T * nblk * ((P + 3) / 4 * 4) * sizeof(float);
 }
 
