@@ -58,6 +58,26 @@ def test_argument_validation_without_gpu(lib):
     assert lib.irs_dynamics_batch(0, p, 1, None, None, 0, None, None) == -1
     assert lib.irs_smooth_finalize(0, p, 1, 9, 30, 10, None, None, None, None, None, None, None, None) == -1
     assert lib.irs_last_error() != b""
+    # the quasistatic entry points: null pointers, an unknown solver, half a bound pair, a workspace
+    # that cannot hold the nominal steps, an analytic model where a position-controlled one is needed
+    ph = dbl_array([0.1, 10.0, 1.0, 0.25, 0.5, 50.0, 25.0, 0.3, 0.2, 0.05, 0.1, 50.0])
+    one = 8     # any non-null address: validation happens before anything is dereferenced
+    args = [one] * 8
+    assert lib.irs_quasistatic_box_descent(4, ph, 12, 10, None, *args[:7], None, None, None, None, None, None,
+                                           0, 10.0, 1.6, 100, 1e-8, one, one, None, one, None) == -1
+    assert lib.irs_quasistatic_box_descent(4, ph, 12, 10, *args, None, None, None, None, None, None,
+                                           7, 10.0, 1.6, 100, 1e-8, one, one, None, one, None) == -1
+    assert lib.irs_quasistatic_box_descent(4, ph, 12, 10, *args, None, None, one, None, None, None,
+                                           0, 10.0, 1.6, 100, 1e-8, one, one, None, one, None) == -1
+    assert lib.irs_quasistatic_box_descent(4, ph, 12, 10, *args, one, one, one, one, None, None,
+                                           2, 10.0, 1.6, 100, 1e-8, one, one, None, one, None) == -3   # active set: one box
+    assert lib.irs_quasistatic_box_lds_bytes(0, 50, 2) == 0                 # the pendulum is not position controlled
+    assert 0 < lib.irs_quasistatic_box_lds_bytes(4, 50, 2) <= 160 * 1024 - 512
+    assert lib.irs_quasistatic_box_lds_bytes(4, 80, 2) > 160 * 1024 - 512   # planar hand: T <= 52 on chip
+    assert 0 < lib.irs_quasistatic_box_lds_bytes(5, 120, 2) <= 160 * 1024 - 512   # box pivoting: its script's horizon fits
+    assert lib.irs_smooth_finalize_ws(4, ph, 12, 2, 50, 100, one, one, one, one, one, one, one, one, 64, None) == -1
+    assert lib.irs_cem_rollout_costs_quasistatic(4, ph, 12, 10, 0, one, one, one, one, one, one, one, None) == -1
+    assert lib.irs_model_info(9, None, None, None) != 0
 
 
 def test_product_does_not_import_oracle():
