@@ -36,6 +36,15 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// 1/d to ~1 ulp: hardware reciprocal + two Newton steps (a correctly rounded f64 divide is ~40
+// dependent instructions, four times on the critical path of every backward step)
+__device__ __forceinline__ double fast_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) v = fmax(v, __shfl_xor(v, s, 64));
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(64) void ctrlbox_descent_kernel(BoxArgs a) {
                 for (int l = 0; l < j; ++l) dj -= Lm[j][l] * Lm[j][l] * Dg[l];
                 if (!(dj > 0.0) && bad == 0) bad = t + 1;
                 Dg[j] = dj;
-                Dinv[j] = 1.0 / dj;
+                Dinv[j] = fast_rcp(dj);
 #pragma unroll
                 for (int i = j + 1; i < M; ++i) {
                     double s = Hm[i * M + j];
