@@ -63,6 +63,9 @@ typedef enum irs_model_id {
                                  controlled disc; x = [x_h, x_b, y_h, y_b, th_b] (box_pivoting_analysis.py:53-64),
                                  u = commanded hand position; params = {h, g, mass, half, mu, kp, r_hand,
                                  pgs_iters}; same contact scheme and restrictions as the planar hand.       */
+    , IRS_MODEL_BOX_ON_BOX = 6 /* examples/box_pushing/analysis/box_on_box.py:11-20: the reference's 1-D
+                                 statement of the quasi-dynamic step (x = [x_a, x_u], u = commanded x_a;
+                                 params = {h, m, k, pgs_iters}); pins the contact QP code the functors share */
 } irs_model_id;
 
 /* Smoothing estimators.                                                         */

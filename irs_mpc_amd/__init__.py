@@ -9,7 +9,8 @@ from .irs_lqr import (IrsLqr, IrsLqrExact, IrsLqrFirstOrder,        # noqa: F401
 from .irs_lqr_quasistatic import (IrsLqrQuasistatic,               # noqa: F401
                                    IrsLqrQuasistaticParameters)
 from .sampling import GaussianSmoothing                             # noqa: F401
-from .systems import (BicycleDynamics, BoxPivotingDynamics,          # noqa: F401
+from .systems import (BicycleDynamics, BoxOnBoxDynamics,             # noqa: F401
+                      BoxPivotingDynamics,
                       PendulumDynamics, PlanarHandDynamics,
                       QuadrotorDynamics, QuasistaticDeviceDynamics,
                       ThreeCartDynamics)

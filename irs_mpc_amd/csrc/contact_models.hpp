@@ -320,3 +320,35 @@ struct BoxPivotModel {
         for (int k = 0; k < NX; ++k) xn_ext[perm(k)] = qn[k];
     }
 };
+
+// examples/box_pushing/analysis/box_on_box.py:11-20 -- the reference's own 1-D statement of the scheme:
+// a stiffness-controlled point (gain k) commanded to u pushes a mass m that sits in front of it.
+//   x = [x_a, x_u], u = commanded x_a; params = {h, m, k, pgs_iters}
+// One frictionless contact x_u - x_a >= 0, entered twice (the dual solver works on generator PAIRS).
+// Exists to pin irs_contact_qp_step -- the code every contact functor shares -- against the closed
+// form printed there: x+ = (m + h^2 k u) / (m + h^2 k) for both bodies once u > x_u.
+struct BoxOnBoxModel {
+    static constexpr int NX = 2, NU = 1, NPARAMS = 4;
+    static constexpr int NC = 2;
+    static constexpr bool HAS_JACOBIAN = false;
+    IRS_HD static int u_into_x(int) { return 0; }
+
+    template <typename S>
+    IRS_HD static void step(const ModelParams& p, const S* q, const S* u, S* qn) {
+        using T = typename scalar_of<S>::type;
+        const T h = T(p.v[0]), m = T(p.v[1]), k = T(p.v[2]);
+        const int iters = (int)p.v[3];
+        T Dinv[NX];
+        Dinv[0] = T(1) / k; Dinv[1] = h * h / m;
+        S b[NX];
+        b[0] = k * (q[0] - u[0]);
+        b[1] = q[1] * T(0);
+        S J[NC][NX], phi[NC];
+#pragma unroll
+        for (int r = 0; r < NC; ++r) {
+            J[r][0] = S(T(-1)); J[r][1] = S(T(1));
+            phi[r] = q[1] - q[0];
+        }
+        irs_contact_qp_step<S, NX, NC>(q, Dinv, b, J, phi, iters, qn);
+    }
+};

@@ -786,6 +786,7 @@ bool is_light(int model, int mode) {
         case IRS_MODEL_THREE_CART: return light_m<ThreeCartModel>(mode);
         case IRS_MODEL_PLANAR_HAND: return light_m<PlanarHandModel>(mode);
         case IRS_MODEL_BOX_PIVOT: return light_m<BoxPivotModel>(mode);
+        case IRS_MODEL_BOX_ON_BOX: return light_m<BoxOnBoxModel>(mode);
     }
     return false;
 }

@@ -1,7 +1,7 @@
 """Device-backed twins of the reference's analytic example plugins."""
 import numpy as np
 
-from ._lib import (MODEL_BICYCLE, MODEL_BOX_PIVOT, MODEL_PENDULUM, MODEL_PLANAR_HAND,
+from ._lib import (MODEL_BICYCLE, MODEL_BOX_ON_BOX, MODEL_BOX_PIVOT, MODEL_PENDULUM, MODEL_PLANAR_HAND,
                    MODEL_QUADROTOR, MODEL_THREE_CART)
 from .dynamical_system import DynamicalSystem
 
@@ -187,3 +187,21 @@ class BoxPivotingDynamics(QuasistaticDeviceDynamics):
 
     def device_params(self):
         return [self.h, self.g, self.mass, self.half, self.mu, self.kp, self.r_hand, float(self.pgs_iters)]
+
+
+class BoxOnBoxDynamics(QuasistaticDeviceDynamics):
+    """The reference's 1-D statement of the quasi-dynamic step (examples/box_pushing/analysis/
+    box_on_box.py:11-20: m = 1, k = 100, h = 0.1): x = [x_a, x_u], u = commanded x_a.  Runs the same
+    device contact-QP code as the planar functors and is checked against the closed form there."""
+    device_model = MODEL_BOX_ON_BOX
+
+    def __init__(self, h=0.1, m=1.0, k=100.0, pgs_iters=4):
+        super().__init__()
+        self.h, self.m, self.k, self.pgs_iters = h, m, k, pgs_iters
+        self.dim_x, self.dim_u = 2, 1
+        self.models_unactuated, self.models_actuated = ["box"], ["pusher"]
+        self.position_indices = {"pusher": np.array([0]), "box": np.array([1])}
+        self._finish_bookkeeping()
+
+    def device_params(self):
+        return [self.h, self.m, self.k, float(self.pgs_iters)]

@@ -25,7 +25,9 @@ functions): the reference steps pangtao22/quasistatic_simulator (external, not v
 files absent; plus Drake and Gurobi), so the contact step restates the published scheme
 (Anitescu's convex quasi-dynamic step) on the constants the reference does state, and the
 bounded du-cost QPs of irs_lqr/tv_lqr.py:96-127 are certified against their own KKT conditions
-instead of a reference run.  See DESIGN.md section 3.
+instead of a reference run.  The scheme itself (and the shared PGS code) IS pinned by the closed
+form the reference prints for its 1-D case, examples/box_pushing/analysis/box_on_box.py:11-20
+(BoxOnBoxOracle).  See DESIGN.md section 3.
 """
 import numpy as np
 
@@ -321,6 +323,32 @@ class _ContactQPOracle:
         raise NotImplementedError("no differentiable step; see zero_order_B_decoupled")
 
     jacobian_xu_batch = jacobian_xu
+
+
+class BoxOnBoxOracle(_ContactQPOracle):
+    """The reference's own 1-D instance of the quasi-dynamic step, examples/box_pushing/analysis/
+    box_on_box.py:11-20: a stiffness-controlled point (k = 100) commanded to u pushes a unit mass that
+    sits at 1; h = 0.1.  x = [x_a, x_u].  Same QP as the planar models (D = diag(K_a, M_u/h^2),
+    b = (K_a (x_a - u), 0), one frictionless contact x_u - x_a >= 0): the closed form stated there,
+    x+ = w1 * 1 + w2 * u with w1 = m/(m + h^2 k), w2 = h^2 k/(m + h^2 k) once u > 1, is the scheme's
+    known answer (tests/test_oracle_golden.py)."""
+
+    PERM = np.array([0, 1])
+
+    def __init__(self, h=0.1, m=1.0, k=100.0, pgs_iters=50):
+        self.h, self.m, self.k, self.pgs_iters = h, m, k, pgs_iters
+        self.dim_x, self.dim_u = 2, 1
+        self.indices_u_into_x = np.array([0])
+
+    def _qp(self, q, u):
+        q, u = np.atleast_2d(q), np.atleast_2d(u)
+        B = q.shape[0]
+        Dinv = np.array([1.0 / self.k, self.h ** 2 / self.m])
+        b = np.zeros((B, 2))
+        b[:, 0] = self.k * (q[:, 0] - u[:, 0])
+        J = np.tile(np.array([[[-1.0, 1.0]]]), (B, 1, 1))
+        phi = (q[:, 1] - q[:, 0])[:, None]
+        return Dinv, b, J, phi
 
 
 class PlanarHandOracle(_ContactQPOracle):

@@ -1213,3 +1213,30 @@ def test_planar_hand_full_size_properties(amd):
         Bo = orc.zero_order_B_fit(sub[t].cpu().numpy().astype(np.float64), fn - sys_o.dynamics(x_np[t], u_np[t]))
         Bo[HAND_IDX, :] = np.eye(4)
         np.testing.assert_allclose(o_sub["Bt"][t].cpu().numpy(), Bo, rtol=0, atol=5e-4)
+
+
+def test_device_contact_qp_reproduces_reference_box_on_box(amd):
+    """The device contact-QP code shared by every contact functor (csrc/contact_models.hpp:
+    irs_contact_qp_step), on the reference's own 1-D example and against the closed form printed there
+    (examples/box_pushing/analysis/box_on_box.py:11-20): m = 1, k = 100, h = 0.1, pusher at 0, box at 1."""
+    from irs_mpc_amd import device as dev
+    from irs_mpc_amd._lib import SMOOTH_ZERO_ORDER_B
+    m, k, h = 1.0, 100.0, 0.1
+    w1 = m / (m + h ** 2.0 * k)                 # box_on_box.py:16
+    w2 = h ** 2.0 * k / (m + h ** 2.0 * k)      # box_on_box.py:17
+    sys_d = amd.BoxOnBoxDynamics(h, m, k)
+    u = np.linspace(-2.0, 2.0, 401)[:, None]
+    X = np.tile(np.array([0.0, 1.0]), (len(u), 1))
+    want = np.where(u > 1, np.hstack([w1 + w2 * u, w1 + w2 * u]), np.hstack([u, np.ones_like(u)]))   # :18 / :20
+    np.testing.assert_allclose(sys_d.dynamics_batch(X, u), want, rtol=0, atol=1e-13)
+    # ... and through the f32 sample pass: deep in contact the smoothed dx_u/du is w2, far from it 0
+    dm = sys_d.dm()
+    x_trj = np.tile(np.array([0.0, 1.0]), (3, 1))
+    u_trj = np.array([[1.8], [-1.0]])
+    du = (0.05 * np.random.default_rng(0).normal(size=(2, 4000, 1))).astype(np.float32)
+    o = dm.smooth(SMOOTH_ZERO_ORDER_B, dev.to_dev(x_trj), dev.to_dev(u_trj), None, dev.to_dev(du, dev.F32))
+    B = o["Bt"].cpu().numpy()
+    np.testing.assert_allclose(B[0, :, 0], [1.0, w2], rtol=0, atol=2e-6)       # pusher row decoupled, box row = w2
+    np.testing.assert_allclose(B[1, :, 0], [1.0, 0.0], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(o["ct"].cpu().numpy()[0], [w1 + w2 * 1.8 - 1.8, w1 + w2 * 1.8 - 1.0 - w2 * 1.8],
+                               rtol=0, atol=2e-6)

@@ -475,3 +475,18 @@ def test_quasistatic_descent_two_solvers_agree():
         assert max(iters) < 40000 and all(st[1] >= 0 for st in stats)
         np.testing.assert_allclose(ua, ub_, rtol=0, atol=1e-8)
         np.testing.assert_allclose(xa, xb, rtol=0, atol=1e-8)
+
+
+def test_contact_scheme_reproduces_reference_box_on_box_closed_form():
+    """The quasi-dynamic step shared by all contact oracles / device functors, on the reference's own
+    1-D example: examples/box_pushing/analysis/box_on_box.py:11-20 states its result in closed form
+    (m = 1, k = 100, h = 0.1, pusher at 0, box at 1).  One PGS sweep is exact for a single contact."""
+    m, k, h = 1.0, 100.0, 0.1
+    o = orc.BoxOnBoxOracle(h, m, k, pgs_iters=1)
+    w1 = m / (m + h ** 2.0 * k)                 # box_on_box.py:16
+    w2 = h ** 2.0 * k / (m + h ** 2.0 * k)      # box_on_box.py:17
+    for u in np.linspace(-2.0, 2.0, 81):
+        got = o.dynamics(np.array([0.0, 1.0]), np.array([u]))
+        want = np.array([w1 * 1.0 + w2 * u] * 2) if u > 1 else np.array([u, 1.0])   # :18 / :20
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(o.dynamics_exact(np.array([0.0, 1.0]), np.array([u])), want, atol=1e-9)
