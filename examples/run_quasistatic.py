@@ -6,6 +6,7 @@
     python examples/run_quasistatic.py planar_hand cem           # .../run_planar_hand_cem.py
     python examples/run_quasistatic.py box_pivoting irs_lqr      # examples/box_pivoting/run_box_pivoting.py
     python examples/run_quasistatic.py box_pivoting cem          # .../run_box_pivoting_cem.py
+    python examples/run_quasistatic.py box_pushing irs_lqr       # examples/box_pushing/run_box_pushing.py
 
 planar_hand: problem data as in run_planar_hand.py:20-153 (h = 0.1, initial grasp, goal
 q_u0 + (0.3, -0.1, 0.5), Q/Qd/R dicts, u_bounds_abs = +-0.5 h, std_u_initial = 0.3 / iter^0.8).
@@ -41,6 +42,20 @@ def box_problem(T, h=0.1):
     return q_dynamics, x0, u_traj_0, Q_dict, Qd_dict, R_dict, np.tile(xd, (T + 1, 1))
 
 
+def push_problem(T, h=0.1):
+    """examples/box_pushing/run_box_pushing.py:20-131."""
+    q_dynamics = amd.BoxPushingDynamics(h)
+    idx_u, idx_a = "box", "hand"
+    q_u0, qa0 = np.array([0.0, 0.5, 0.0]), np.array([0.0, -0.2])
+    x0 = q_dynamics.get_x_from_q_dict({idx_u: q_u0, idx_a: qa0})
+    u_traj_0 = np.tile(qa0, (T, 1))                               # :24-27 (hold)
+    Q_dict = {idx_u: np.array([3.0, 3.0, 1.2]), idx_a: np.array([0.0, 0.0])}            # :101-103
+    Qd_dict = {model: Q_i * 0 for model, Q_i in Q_dict.items()}                        # :104
+    R_dict = {idx_a: 1e1 * np.array([1, 1])}                                           # :105
+    xd = q_dynamics.get_x_from_q_dict({idx_u: q_u0 + np.array([0.5, 0.5, -np.pi / 4]), idx_a: qa0})   # :107-109
+    return q_dynamics, x0, u_traj_0, Q_dict, Qd_dict, R_dict, np.tile(xd, (T + 1, 1))
+
+
 def problem(T, h=0.1):
     q_dynamics = amd.PlanarHandDynamics(h)
     idx_u, idx_a_l, idx_a_r = "sphere", "arm_left", "arm_right"
@@ -57,7 +72,7 @@ def problem(T, h=0.1):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("system", choices=["planar_hand", "box_pivoting"])
+    ap.add_argument("system", choices=["planar_hand", "box_pivoting", "box_pushing"])
     ap.add_argument("method", choices=["irs_lqr", "cem"])
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--T", type=int, default=30)
@@ -72,7 +87,8 @@ def main():
 
     h = 0.1
     hand = a.system == "planar_hand"
-    q_dynamics, x0, u_traj_0, Q_dict, Qd_dict, R_dict, x_trj_d = (problem if hand else box_problem)(a.T, h)
+    make = {"planar_hand": problem, "box_pivoting": box_problem, "box_pushing": push_problem}[a.system]
+    q_dynamics, x0, u_traj_0, Q_dict, Qd_dict, R_dict, x_trj_d = make(a.T, h)
     if a.bounds is None:
         a.bounds = "abs" if hand else "rel"
     np.random.seed(a.seed)
@@ -83,11 +99,14 @@ def main():
         dim_u = q_dynamics.dim_u
         if a.bounds == "abs":       # run_planar_hand.py:138-139
             params.u_bounds_abs = np.array([-np.ones(dim_u) * 0.5 * h, np.ones(dim_u) * 0.5 * h])
-        elif a.bounds == "rel":     # run_box_pivoting.py:119-120 (0.15 h); run_box_pushing.py:117
-            w = 0.3 * h if hand else 0.15 * h
+        elif a.bounds == "rel":     # run_box_pivoting.py:119-120 (0.15 h); run_box_pushing.py:117-118 (0.4 h)
+            w = 0.3 * h if hand else (0.4 * h if a.system == "box_pushing" else 0.15 * h)
             params.u_bounds_rel = np.array([-np.ones(dim_u) * w, np.ones(dim_u) * w])
         if hand:
             params.sampling = lambda u_initial, it: u_initial / (it ** 0.8)     # run_planar_hand.py:142-146
+            params.std_u_initial = np.ones(dim_u) * 0.3
+        elif a.system == "box_pushing":
+            params.sampling = lambda u_initial, it: u_initial ** (1.0 * it)     # run_box_pushing.py:120-124
             params.std_u_initial = np.ones(dim_u) * 0.3
         else:
             params.sampling = lambda u_initial, it: u_initial ** (0.5 * it)     # run_box_pivoting.py:122-126

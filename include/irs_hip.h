@@ -66,6 +66,10 @@ typedef enum irs_model_id {
     , IRS_MODEL_BOX_ON_BOX = 6 /* examples/box_pushing/analysis/box_on_box.py:11-20: the reference's 1-D
                                  statement of the quasi-dynamic step (x = [x_a, x_u], u = commanded x_a;
                                  params = {h, m, k, pgs_iters}); pins the contact QP code the functors share */
+    , IRS_MODEL_BOX_PUSH = 7  /* examples/box_pushing (box_pushing_setup.py:6-19): the box and disc of
+                                 box_pivoting seen from above (no gravity, no ground, Kp = 500); x, u as there;
+                                 params = {h, mass, inertia, half, mu, kp, r_hand, pgs_iters}.  PINNED by the
+                                 simulator data examples/box_pushing/analysis/{xu,dxdu}_quasistatic.npy        */
 } irs_model_id;
 
 /* Smoothing estimators.                                                         */

@@ -10,7 +10,7 @@ from .irs_lqr_quasistatic import (IrsLqrQuasistatic,               # noqa: F401
                                    IrsLqrQuasistaticParameters)
 from .sampling import GaussianSmoothing                             # noqa: F401
 from .systems import (BicycleDynamics, BoxOnBoxDynamics,             # noqa: F401
-                      BoxPivotingDynamics,
+                      BoxPivotingDynamics, BoxPushingDynamics,
                       PendulumDynamics, PlanarHandDynamics,
                       QuadrotorDynamics, QuasistaticDeviceDynamics,
                       ThreeCartDynamics)

@@ -19,6 +19,7 @@ MODEL_THREE_CART = 3
 MODEL_PLANAR_HAND = 4
 MODEL_BOX_PIVOT = 5
 MODEL_BOX_ON_BOX = 6
+MODEL_BOX_PUSH = 7
 SMOOTH_ZERO_ORDER_AB = 0
 SMOOTH_FIRST_ORDER = 1
 SMOOTH_ZERO_ORDER_B = 2

@@ -209,6 +209,54 @@ struct PlanarHandModel {
     }
 };
 
+
+// Rows of a disc ("hand", radius rh, centre (q[3], q[4])) against a square box (half side a, centre
+// (q[0], q[1]), angle q[2]; sn, cs = sin / cos of the angle): two friction-cone generators n +- mu t of
+// the pair, written to J[row0], J[row0 + 1] and phi.  Nearest point of the outline by clamping in the
+// box frame; a disc centre inside or ON the outline (the reference's box_pivoting start) takes the
+// nearest face.  q = [xb, yb, th, xh, yh].
+template <typename S, typename T>
+IRS_HD void irs_hand_box_rows(const S* q, const S& sn, const S& cs, T a, T rh, T mu, S (*J)[5], S* phi, int row0) {
+    const S dx = q[3] - q[0], dy = q[4] - q[1];
+    const S px = cs * dx + sn * dy, py = -sn * dx + cs * dy;     // hand centre in the box frame
+    const T pxv = irs_value(px), pyv = irs_value(py);
+    const bool outside = fabs(pxv) > a || fabs(pyv) > a;
+    // outside: nearest point = clamp; inside or on the boundary: the nearest face
+    const S cxq = irs_select(pxv > a, S(a), irs_select(pxv < -a, S(-a), px));
+    const S cyq = irs_select(pyv > a, S(a), irs_select(pyv < -a, S(-a), py));
+    const T ddx = a - fabs(pxv), ddy = a - fabs(pyv);           // penetration depths (inside)
+    const bool facex = ddx <= ddy;
+    const T sgx = pxv >= T(0) ? T(1) : T(-1), sgy = pyv >= T(0) ? T(1) : T(-1);
+    S qlx, qly, nlx, nly, dist;
+    if (outside) {
+        const S ex = px - cxq, ey = py - cyq;
+        dist = irs_sqrt(ex * ex + ey * ey);
+        nlx = ex / dist; nly = ey / dist;
+        qlx = cxq; qly = cyq;
+    } else {
+        qlx = facex ? S(sgx * a) : px;
+        qly = facex ? py : S(sgy * a);
+        nlx = S(facex ? sgx : T(0));
+        nly = S(facex ? T(0) : sgy);
+        dist = S(-(facex ? ddx : ddy));
+    }
+    const S gap = dist - rh;
+    const S nx = cs * nlx - sn * nly, ny = sn * nlx + cs * nly;  // box -> hand, world frame
+    const S rx = cs * qlx - sn * qly, ry = sn * qlx + cs * qly;  // contact point - box centre
+#pragma unroll
+    for (int gen = 0; gen < 2; ++gen) {
+        const int row = row0 + gen;
+        const T sg = gen == 0 ? mu : -mu;
+        const S ex = nx - ny * sg, ey = ny + nx * sg;            // e = n + sg t, t = (-ny, nx)
+        phi[row] = gap;
+        J[row][0] = -ex;
+        J[row][1] = -ey;
+        J[row][2] = -(ey * rx - ex * ry);
+        J[row][3] = ex;
+        J[row][4] = ey;
+    }
+}
+
 // examples/box_pivoting: a 1 m square box on the ground, pushed / pivoted by a position-controlled
 // disc ("hand", radius 0.1; examples/box_pivoting/analysis/box_pivoting_analysis.py:34-72).
 //   x = [x_h, x_b, y_h, y_b, th_b]   -- the reference's state order (box_pivoting_analysis.py:53-64)
@@ -265,46 +313,7 @@ struct BoxPivotModel {
             }
         }
         // rows 8..9: hand against the box
-        {
-            const S dx = q[3] - q[0], dy = q[4] - q[1];
-            const S px = cs * dx + sn * dy, py = -sn * dx + cs * dy;     // hand centre in the box frame
-            const T pxv = irs_value(px), pyv = irs_value(py);
-            const bool outside = fabs(pxv) > a || fabs(pyv) > a;
-            // outside: nearest point = clamp; inside or on the boundary: the nearest face
-            const S cxq = irs_select(pxv > a, S(a), irs_select(pxv < -a, S(-a), px));
-            const S cyq = irs_select(pyv > a, S(a), irs_select(pyv < -a, S(-a), py));
-            const T ddx = a - fabs(pxv), ddy = a - fabs(pyv);           // penetration depths (inside)
-            const bool facex = ddx <= ddy;
-            const T sgx = pxv >= T(0) ? T(1) : T(-1), sgy = pyv >= T(0) ? T(1) : T(-1);
-            S qlx, qly, nlx, nly, dist;
-            if (outside) {
-                const S ex = px - cxq, ey = py - cyq;
-                dist = irs_sqrt(ex * ex + ey * ey);
-                nlx = ex / dist; nly = ey / dist;
-                qlx = cxq; qly = cyq;
-            } else {
-                qlx = facex ? S(sgx * a) : px;
-                qly = facex ? py : S(sgy * a);
-                nlx = S(facex ? sgx : T(0));
-                nly = S(facex ? T(0) : sgy);
-                dist = S(-(facex ? ddx : ddy));
-            }
-            const S gap = dist - rh;
-            const S nx = cs * nlx - sn * nly, ny = sn * nlx + cs * nly;  // box -> hand, world frame
-            const S rx = cs * qlx - sn * qly, ry = sn * qlx + cs * qly;  // contact point - box centre
-#pragma unroll
-            for (int gen = 0; gen < 2; ++gen) {
-                const int row = 8 + gen;
-                const T sg = gen == 0 ? mu : -mu;
-                const S ex = nx - ny * sg, ey = ny + nx * sg;            // e = n + sg t, t = (-ny, nx)
-                phi[row] = gap;
-                J[row][0] = -ex;
-                J[row][1] = -ey;
-                J[row][2] = -(ey * rx - ex * ry);
-                J[row][3] = ex;
-                J[row][4] = ey;
-            }
-        }
+        irs_hand_box_rows<S, T>(q, sn, cs, a, rh, mu, J, phi, 8);
         // rows 10..11: hand against the ground
 #pragma unroll
         for (int gen = 0; gen < 2; ++gen) {
@@ -350,5 +359,43 @@ struct BoxOnBoxModel {
             phi[r] = q[1] - q[0];
         }
         irs_contact_qp_step<S, NX, NC>(q, Dinv, b, J, phi, iters, qn);
+    }
+};
+
+// examples/box_pushing (box_pushing_setup.py:6-19): the same box and disc seen from above -- no gravity,
+// no ground, Kp = 500.  PINNED by the simulator data the reference ships,
+// examples/box_pushing/analysis/{xu,dxdu}_quasistatic.npy (tests/golden/box_pushing_*.npy): the 80-step
+// push and the simulator's input Jacobians; they identify mass = 5, inertia = 1/6, r_hand = 0.0995.
+//   x = [x_h, x_b, y_h, y_b, th_b], u = commanded hand position
+//   params = {h, mass, inertia, half, mu, kp, r_hand, pgs_iters}
+struct BoxPushModel {
+    static constexpr int NX = 5, NU = 2, NPARAMS = 8;
+    static constexpr int NC = 2;
+    static constexpr bool HAS_JACOBIAN = false;
+    IRS_HD static constexpr int perm(int k) { return BoxPivotModel::perm(k); }
+    IRS_HD static int u_into_x(int j) { return perm(3 + j); }
+
+    template <typename S>
+    IRS_HD static void step(const ModelParams& p, const S* x_ext, const S* u, S* xn_ext) {
+        using T = typename scalar_of<S>::type;
+        const T h = T(p.v[0]), mass = T(p.v[1]), inertia = T(p.v[2]), a = T(p.v[3]), mu = T(p.v[4]);
+        const T kp = T(p.v[5]), rh = T(p.v[6]);
+        const int iters = (int)p.v[7];
+        S q[NX], qn[NX];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) q[k] = x_ext[perm(k)];
+        T Dinv[NX];
+        Dinv[0] = h * h / mass; Dinv[1] = h * h / mass; Dinv[2] = h * h / inertia;
+        Dinv[3] = T(1) / kp; Dinv[4] = T(1) / kp;
+        S b[NX];
+        b[0] = S(T(0)); b[1] = S(T(0)); b[2] = S(T(0));
+        b[3] = kp * (q[3] - u[0]); b[4] = kp * (q[4] - u[1]);
+        S J[NC][NX], phi[NC];
+        S sn, cs;
+        irs_sincos(q[2], sn, cs);
+        irs_hand_box_rows<S, T>(q, sn, cs, a, rh, mu, J, phi, 0);
+        irs_contact_qp_step<S, NX, NC>(q, Dinv, b, J, phi, iters, qn);
+#pragma unroll
+        for (int k = 0; k < NX; ++k) xn_ext[perm(k)] = qn[k];
     }
 };

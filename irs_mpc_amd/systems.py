@@ -1,7 +1,8 @@
 """Device-backed twins of the reference's analytic example plugins."""
 import numpy as np
 
-from ._lib import (MODEL_BICYCLE, MODEL_BOX_ON_BOX, MODEL_BOX_PIVOT, MODEL_PENDULUM, MODEL_PLANAR_HAND,
+from ._lib import (MODEL_BICYCLE, MODEL_BOX_ON_BOX, MODEL_BOX_PIVOT, MODEL_BOX_PUSH, MODEL_PENDULUM,
+                   MODEL_PLANAR_HAND,
                    MODEL_QUADROTOR, MODEL_THREE_CART)
 from .dynamical_system import DynamicalSystem
 
@@ -205,3 +206,22 @@ class BoxOnBoxDynamics(QuasistaticDeviceDynamics):
 
     def device_params(self):
         return [self.h, self.m, self.k, float(self.pgs_iters)]
+
+
+class BoxPushingDynamics(BoxPivotingDynamics):
+    """Device twin of `QuasistaticDynamics` for examples/box_pushing (box_pushing_setup.py:6-19,
+    run_box_pushing.py:20-75): the box and disc of box_pivoting seen from above -- no gravity, no
+    ground, Kp = 500.  x = [x_h, x_b, y_h, y_b, th_b], u = commanded hand position.  PINNED: mass 5,
+    inertia 1/6 and r_hand 0.0995 are identified from -- and the step reproduces to 1e-8 -- the
+    simulator trajectory the reference ships (examples/box_pushing/analysis/xu_quasistatic.npy)."""
+    device_model = MODEL_BOX_PUSH
+
+    def __init__(self, h=0.1, mass=5.0, inertia=1.0 / 6.0, mu=0.5, pgs_iters=50):
+        super().__init__(h, mass, mu, pgs_iters)
+        self.g = 0.0             # box_pushing_setup.py:18
+        self.inertia = inertia
+        self.kp = 500.0          # box_pushing_setup.py:10
+        self.r_hand = 0.0995
+
+    def device_params(self):
+        return [self.h, self.mass, self.inertia, self.half, self.mu, self.kp, self.r_hand, float(self.pgs_iters)]

@@ -20,8 +20,11 @@ dependency that is not vendored and not installed; solve_tvlqr_qp() below
 restates the QP exactly as posed and solves its KKT system directly (valid while
 the box bounds are inactive), and the two *_exact.csv files anchor it.
 
-PARITY UNPINNED for the quasistatic part (PlanarHandOracle and the *_quasistatic / ctrlbox_*
-functions): the reference steps pangtao22/quasistatic_simulator (external, not vendored, model
+Quasistatic part -- the contact STEP is PINNED by simulator data the reference ships
+(examples/box_pushing/analysis/{xu,dxdu}_quasistatic.npy -> BoxPushOracle: 80-step trajectory and
+input Jacobians) and by the closed form of its 1-D case (box_on_box.py:11-20 -> BoxOnBoxOracle).
+PARITY UNPINNED for the planar-hand / box-pivoting geometry and parameters (PlanarHandOracle,
+BoxPivotOracle) and for the *_quasistatic / ctrlbox_* functions: the reference steps pangtao22/quasistatic_simulator (external, not vendored, model
 files absent; plus Drake and Gurobi), so the contact step restates the published scheme
 (Anitescu's convex quasi-dynamic step) on the constants the reference does state, and the
 bounded du-cost QPs of irs_lqr/tv_lqr.py:96-127 are certified against their own KKT conditions
@@ -463,11 +466,14 @@ class BoxPivotOracle(_ContactQPOracle):
 
     PERM = np.array([1, 3, 4, 0, 2])
 
+    ground = True            # contacts with the ground y = 0 (and gravity) present
+
     def __init__(self, h, mass=1.0, mu=0.5, pgs_iters=50):
         self.h = h
         self.dim_x, self.dim_u = 5, 2
         self.g = 9.81
         self.mass, self.half, self.mu = mass, 0.5, mu
+        self.inertia = mass * (2 * self.half) ** 2 / 6.0      # square plate
         self.kp = 50000.0
         self.r_hand = 0.1
         self.pgs_iters = pgs_iters
@@ -487,8 +493,7 @@ class BoxPivotOracle(_ContactQPOracle):
         u = np.atleast_2d(u)
         B = q.shape[0]
         h, m, a, mu, kp, rh = self.h, self.mass, self.half, self.mu, self.kp, self.r_hand
-        inertia = m * (2 * a) ** 2 / 6.0
-        Dinv = np.array([h * h / m, h * h / m, h * h / inertia, 1 / kp, 1 / kp])
+        Dinv = np.array([h * h / m, h * h / m, h * h / self.inertia, 1 / kp, 1 / kp])
         b = np.zeros((B, 5))
         b[:, 1] = m * self.g
         b[:, 3] = kp * (q[:, 3] - u[:, 0])
@@ -529,7 +534,32 @@ class BoxPivotOracle(_ContactQPOracle):
             row, sg = 10 + gen, (mu if gen == 0 else -mu)
             phi[:, row] = q[:, 4] - rh
             J[:, row, 3], J[:, row, 4] = sg, 1.0
+        if not self.ground:
+            J, phi = J[:, 8:10], phi[:, 8:10]        # only the hand-box pair
         return Dinv, b, J, phi
+
+
+class BoxPushOracle(BoxPivotOracle):
+    """examples/box_pushing (box_pushing_setup.py:6-19, run_box_pushing.py:20-75): the same square box
+    and disc hand seen from above -- no gravity (setup :18), no ground, Kp = 500 (:10).  PINNED by the
+    reference's own simulator data, examples/box_pushing/analysis/{xu,dxdu}_quasistatic.npy (committed
+    as tests/golden/box_pushing_*.npy): an 80-step straight push recorded from the quasistatic
+    simulator, row t+1 = (step(row t's state, row t+1's command), that command), plus the simulator's
+    Jacobians.  The data identify the parameters the absent SDF/YAML would hold: box mass 5
+    (= Kp h^2: hand and box share the first contact displacement equally), inertia 1/6 (the lateral
+    Jacobian entries), touching distance 0.5995 (half + r_hand; r_hand = 0.0995)."""
+
+    ground = False
+
+    def __init__(self, h=0.1, mass=5.0, inertia=1.0 / 6.0, mu=0.5, pgs_iters=50):
+        super().__init__(h, mass, mu, pgs_iters)
+        self.g = 0.0
+        self.inertia = inertia
+        self.kp = 500.0
+        self.r_hand = 0.0995
+
+    def params(self):
+        return [self.h, self.mass, self.inertia, self.half, self.mu, self.kp, self.r_hand, self.pgs_iters]
 
 
 def zero_order_B_decoupled(system, x_trj, u_trj, du):
@@ -551,7 +581,7 @@ def zero_order_B_decoupled(system, x_trj, u_trj, du):
 
 
 SYSTEMS = {"pendulum": PendulumOracle, "quadrotor": QuadrotorOracle, "bicycle": BicycleOracle,
-           "three_cart": ThreeCartOracle, "planar_hand": PlanarHandOracle, "box_pivoting": BoxPivotOracle}
+           "three_cart": ThreeCartOracle, "planar_hand": PlanarHandOracle, "box_pivoting": BoxPivotOracle, "box_pushing": BoxPushOracle}
 
 
 # --------------------------------------------------------------------------

@@ -258,5 +258,18 @@ def main():
         print("copied", dst)
 
 
+# ---- simulator data the reference ships (quasistatic_simulator outputs; data, not source) ------------
+# examples/box_pushing/analysis/{xu,dxdu}_quasistatic.npy: an 80-step push recorded from the external
+# quasistatic simulator (rows [x_t, u_t] with x_t = step(x_{t-1}, u_t)) and the simulator's
+# Jacobians [Dq_next/Dq | Dq_next/Dq_a_cmd] at those points.  Copied verbatim: they pin the contact step.
+def copy_box_pushing_data():
+    import shutil
+    src = os.path.join(REF, "examples", "box_pushing", "analysis")
+    for name in ("xu_quasistatic.npy", "dxdu_quasistatic.npy"):
+        shutil.copyfile(os.path.join(src, name), os.path.join(HERE, "box_pushing_" + name))
+        print("copied", "box_pushing_" + name)
+
+
 if __name__ == "__main__":
     main()
+    copy_box_pushing_data()

@@ -967,7 +967,8 @@ def test_cem_quasistatic_vs_oracle(amd):
                                    "--device-rng"],
                                   ["planar_hand", "cem", "--iters", "3", "--T", "12", "--N", "60"],
                                   ["box_pivoting", "irs_lqr", "--iters", "3", "--T", "40", "--N", "500"],
-                                  ["box_pivoting", "cem", "--iters", "3", "--T", "40", "--N", "80"]])
+                                  ["box_pivoting", "cem", "--iters", "3", "--T", "40", "--N", "80"],
+                                  ["box_pushing", "irs_lqr", "--iters", "3", "--T", "40", "--N", "500"]])
 def test_quasistatic_example_runner(amd, argv, monkeypatch, capsys):
     """Twins of examples/planar_hand/run_planar_hand{,_cem}.py and examples/box_pivoting/
     run_box_pivoting{,_cem}.py run end to end and descend."""
@@ -1240,3 +1241,48 @@ def test_device_contact_qp_reproduces_reference_box_on_box(amd):
     np.testing.assert_allclose(B[1, :, 0], [1.0, 0.0], rtol=0, atol=2e-6)
     np.testing.assert_allclose(o["ct"].cpu().numpy()[0], [w1 + w2 * 1.8 - 1.8, w1 + w2 * 1.8 - 1.0 - w2 * 1.8],
                                rtol=0, atol=2e-6)
+
+
+# ---------------------------------------------------------------- box pushing: PINNED by the reference's simulator data
+def _box_pushing_data(golden_dir):
+    xu = np.load(os.path.join(golden_dir, "box_pushing_xu_quasistatic.npy"))
+    J = np.load(os.path.join(golden_dir, "box_pushing_dxdu_quasistatic.npy"))
+    return xu[:, :5], xu[:, 5:], J
+
+
+def test_device_contact_step_reproduces_simulator_trajectory(amd, golden_dir):
+    """The device contact functor against REAL simulator output: the 80-step push shipped as
+    examples/box_pushing/analysis/xu_quasistatic.npy (row t = [step(x_{t-1}, u_t), u_t]) -- every
+    transition in one batch, and the whole trajectory as a device rollout."""
+    from irs_mpc_amd import device as dev
+    x, u, _ = _box_pushing_data(golden_dir)
+    sys_d = amd.BoxPushingDynamics(0.1)
+    np.testing.assert_allclose(sys_d.dynamics_batch(x[:-1], u[1:]), x[1:], rtol=0, atol=3e-8)
+    dm = sys_d.dm()
+    x_trj, _ = dm.rollout_cost(dev.to_dev(x[0]), dev.to_dev(u[1:]), dev.to_dev(np.eye(5)), dev.to_dev(np.eye(2)),
+                               dev.to_dev(np.zeros((80, 5))))
+    np.testing.assert_allclose(x_trj.cpu().numpy(), x, rtol=0, atol=2e-7)
+
+
+def test_device_smoothing_matches_simulator_input_jacobian(amd, golden_dir):
+    """Zero-order-B smoothing (N = 20000 f32 contact steps per point, small std) of the pinned functor
+    against the simulator's own Dq_next/Dq_a_cmd (dxdu_quasistatic.npy[:, :, 5:]) at points of the
+    recorded push away from the contact onset: free flight and sticking contact (the hand drags and
+    turns the box through the friction rows).  Box rows only: decouple_AB overwrites the hand rows."""
+    from irs_mpc_amd import device as dev
+    from irs_mpc_amd._lib import SMOOTH_ZERO_ORDER_B
+    x, u, J = _box_pushing_data(golden_dir)
+    pts = [5, 12, 30, 40, 60, 78]
+    sys_d = amd.BoxPushingDynamics(0.1)
+    dm = sys_d.dm()
+    # the smoothing call linearises step(x_trj[t], u_trj[t]): the recorded pairs are (x_{t-1}, u_t)
+    x_trj = np.vstack([x[[t - 1 for t in pts]], x[pts[-1]][None]])
+    u_trj = u[pts]
+    du = (1e-3 * np.random.default_rng(4).normal(size=(len(pts), 20000, 2))).astype(np.float32)
+    o = dm.smooth(SMOOTH_ZERO_ORDER_B, dev.to_dev(x_trj), dev.to_dev(u_trj), None, dev.to_dev(du, dev.F32))
+    assert int(o["info"].abs().sum().item()) == 0
+    B = o["Bt"].cpu().numpy()
+    box_rows = [1, 3, 4]
+    for k, t in enumerate(pts):
+        np.testing.assert_allclose(B[k][box_rows], J[t][box_rows, 5:], rtol=0, atol=3e-3, err_msg="t=%d" % t)
+    assert abs(B[3][4, 0] - 1.58) < 5e-3 and abs(B[3][3, 1] - 0.5) < 1e-3      # t = 40: dragging and pushing

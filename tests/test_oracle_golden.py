@@ -490,3 +490,51 @@ def test_contact_scheme_reproduces_reference_box_on_box_closed_form():
         want = np.array([w1 * 1.0 + w2 * u] * 2) if u > 1 else np.array([u, 1.0])   # :18 / :20
         np.testing.assert_allclose(got, want, rtol=0, atol=1e-13)
         np.testing.assert_allclose(o.dynamics_exact(np.array([0.0, 1.0]), np.array([u])), want, atol=1e-9)
+
+
+def _box_pushing_data(golden_dir):
+    xu = np.load(os.path.join(golden_dir, "box_pushing_xu_quasistatic.npy"))
+    J = np.load(os.path.join(golden_dir, "box_pushing_dxdu_quasistatic.npy"))
+    return xu[:, :5], xu[:, 5:], J
+
+
+def test_box_pushing_step_reproduces_simulator_trajectory(golden_dir):
+    """PIN of the contact step: the 80-step push the reference recorded from the quasistatic simulator
+    (examples/box_pushing/analysis/xu_quasistatic.npy; row t = [step(x_{t-1}, u_t), u_t]) is reproduced
+    step by step -- free motion, contact onset (hand and box share the displacement: M/h^2 = Kp) and
+    steady pushing -- to the simulator's own QP tolerance."""
+    x, u, _ = _box_pushing_data(golden_dir)
+    o = orc.BoxPushOracle(0.1)
+    assert np.abs(x[:, [0, 1, 4]]).max() < 1e-12 and np.abs(u[:, 0]).max() == 0      # a straight push
+    onset = int(np.argmax(x[:, 3] > 0.5 + 1e-6))
+    assert 10 < onset < 30
+    for t in range(len(x) - 1):
+        np.testing.assert_allclose(o.dynamics(x[t], u[t + 1]), x[t + 1], rtol=0, atol=3e-8)
+        np.testing.assert_allclose(o.dynamics_exact(x[t], u[t + 1]), x[t + 1], rtol=0, atol=3e-8)
+    # the whole trajectory as an open-loop rollout from the first state
+    xr = orc.rollout(o, x[0], u[1:])
+    np.testing.assert_allclose(xr, x, rtol=0, atol=2e-7)
+
+
+def test_box_pushing_input_jacobian_matches_simulator(golden_dir):
+    """The simulator's Dq_next/Dq_a_cmd (dxdu_quasistatic.npy[:, :, 5:]) against central differences of
+    the restated step: free flight (identity rows), and sticking contact, where the hand drags and turns
+    the box through the friction-cone rows (0.8946 / 0.1054 / 1.58: they fix inertia/mass = 1/30).  The
+    simulator's state Jacobian holds the contact geometry fixed, so only its geometry-free part (the y
+    rows) is compared."""
+    x, u, J = _box_pushing_data(golden_dir)
+    o = orc.BoxPushOracle(0.1)
+
+    def fd(xs, us, eps=1e-6):
+        out, z = np.zeros((5, 7)), np.concatenate([xs, us])
+        for j in range(7):
+            e = np.zeros(7)
+            e[j] = eps
+            out[:, j] = (o.dynamics_exact((z + e)[:5], (z + e)[5:]) - o.dynamics_exact((z - e)[:5], (z - e)[5:])) / (2 * eps)
+        return out
+
+    for t in (5, 12, 30, 40, 60, 79):
+        Jf = fd(x[t], u[t])
+        np.testing.assert_allclose(Jf[:, 5:], J[t][:, 5:], rtol=0, atol=1.5e-3)       # B, all rows
+        np.testing.assert_allclose(Jf[[2, 3]], J[t][[2, 3]], rtol=0, atol=1e-4)        # y rows of [A | B]
+    assert abs(J[40][4, 5] - 1.5799) < 1e-3 and abs(J[40][2, 6] - 0.5) < 1e-6          # the data really are in contact
