@@ -37,11 +37,11 @@ IRS_HD S irs_max0(const S& a) { return irs_value(a) > 0 ? a : S(a * (typename sc
 // -- a 4-deep dependent chain and NC independent FMAs (NC/2 packed ones in f32) instead of an
 // NC-term dot product per update.  Fixed sweep count: deterministic, branch-free per sample.
 template <typename S, int NX, int NC>
-IRS_HD void irs_contact_qp_step(const S* q, const typename scalar_of<S>::type* Dinv, const S* b,
-                                const S (*J)[NX], const S* phi, int iters, S* qn) {
+IRS_HD void irs_contact_qp_dual(const typename scalar_of<S>::type* Dinv, const S* b, const S (*J)[NX],
+                                const S* phi, int iters, S (*W)[NC], S* lam) {
     using T = typename scalar_of<S>::type;
     static_assert(NC % 2 == 0, "friction generators come in pairs");
-    S W[NC][NC], r[NC], lam[NC], invW[NC], JD[NC][NX], Db[NX];
+    S r[NC], invW[NC], JD[NC][NX], Db[NX];
 #pragma unroll
     for (int k = 0; k < NX; ++k) Db[k] = b[k] * Dinv[k];
 #pragma unroll
@@ -99,12 +99,157 @@ IRS_HD void irs_contact_qp_step(const S* q, const typename scalar_of<S>::type* D
             }
         }
     }
+}
+
+template <typename S, int NX, int NC>
+IRS_HD void irs_contact_qp_primal(const S* q, const typename scalar_of<S>::type* Dinv, const S* b,
+                                  const S (*J)[NX], const S* lam, S* qn) {
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
         S f = -b[k];
 #pragma unroll
         for (int i = 0; i < NC; ++i) f = f + J[i][k] * lam[i];
         qn[k] = q[k] + f * Dinv[k];
+    }
+}
+
+template <typename S, int NX, int NC>
+IRS_HD void irs_contact_qp_step(const S* q, const typename scalar_of<S>::type* Dinv, const S* b,
+                                const S (*J)[NX], const S* phi, int iters, S* qn) {
+    S W[NC][NC], lam[NC];
+    irs_contact_qp_dual<S, NX, NC>(Dinv, b, J, phi, iters, W, lam);
+    irs_contact_qp_primal<S, NX, NC>(q, Dinv, b, J, lam, qn);
+}
+
+// Derivative of the step through its ACTIVE constraints, contact geometry (J) held fixed -- what the
+// reference reads from the simulator after `step(..., requires_grad=True, grad_from_active_constraints=True)`:
+// q_sim.get_Dq_nextDq() | q_sim.get_Dq_nextDqa_cmd() (irs_lqr/quasistatic_dynamics.py:143-164, 184-191).
+// With I = {i : lam_i W_ii > kContactActiveTol}, W_II = J_I D^-1 J_I':
+//     S  = J_I' W_II^+ J_I    (b enters linearly:                    d dq / d b     = -D^-1 + D^-1 S D^-1)
+//     Sn = J_I' W_II^+ Jn_I   (phi_i is a gap, d phi_i / d q = the NORMAL row Jn_i = mean of the contact's
+//                              two generator rows:                   d dq / d phi_I = -D^-1 J_I' W_II^+)
+// and b_a = K (q_a - u), D_aa = K on the actuated dofs `act[j]`, so in the internal coordinate order
+//     B = E_a - D^-1 S[:, a],        A[:, l] = e_l - [l = a_j] B[:, j] - D^-1 Sn[:, l].
+// W_II is factorised IN PLACE (W is destroyed) by a masked LDL' in row order: inactive rows get a zero
+// inverse pivot, and so does an active row that depends on earlier ones (pivot < kContactPivotTol W_ii);
+// the projector S does not depend on which dependent row is dropped.  Pinned by the simulator's own
+// Jacobians, examples/box_pushing/analysis/dxdu_quasistatic.npy (tests/).  T = float or double only.
+constexpr double kContactActiveTol = 1e-7;
+constexpr double kContactPivotTol = 1e-5;
+
+template <typename T, int NX, int NC, int NA, bool WITH_A>
+IRS_HD void irs_contact_qp_grad(const T* Dinv, const T (*J)[NX], T (*W)[NC], const T* lam, const int* act,
+                                T (*Bint)[NA], T (*Aint)[NX]) {
+    constexpr int NR = NA + (WITH_A ? NX : 0);       // right-hand sides: J[:, act] and (for A) Jn
+    T inv[NC], Y[NC][NR];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+#pragma unroll
+        for (int c = 0; c < NA; ++c) Y[i][c] = J[i][act[c]];
+        if constexpr (WITH_A) {
+#pragma unroll
+            for (int l = 0; l < NX; ++l) Y[i][NA + l] = T(0.5) * (J[i & ~1][l] + J[i | 1][l]);
+        }
+    }
+    // masked LDL': unit lower factor kept in the UPPER triangle (W[j][i] = L_ij), the lower one holds the
+    // running Schur complement
+    T Wd[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) Wd[j] = W[j][j];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const T dj = W[j][j];
+        const bool ok = (lam[j] * Wd[j] > T(kContactActiveTol)) && (dj > T(kContactPivotTol) * Wd[j]);
+        inv[j] = ok ? T(1) / dj : T(0);
+#pragma unroll
+        for (int i = j + 1; i < NC; ++i) W[j][i] = W[i][j] * inv[j];
+#pragma unroll
+        for (int i = j + 1; i < NC; ++i)
+#pragma unroll
+            for (int k = j + 1; k <= i; ++k) W[i][k] = W[i][k] - W[j][i] * W[k][j];
+    }
+#pragma unroll
+    for (int c = 0; c < NR; ++c) {
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            T y = Y[j][c];
+#pragma unroll
+            for (int k = 0; k < j; ++k) y = y - W[k][j] * Y[k][c];
+            Y[j][c] = y;
+        }
+#pragma unroll
+        for (int j = NC - 1; j >= 0; --j) {
+            T y = Y[j][c] * inv[j];
+#pragma unroll
+            for (int i = j + 1; i < NC; ++i) y = y - W[j][i] * Y[i][c];
+            Y[j][c] = y;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+#pragma unroll
+        for (int c = 0; c < NA; ++c) {
+            T s = T(0);
+#pragma unroll
+            for (int i = 0; i < NC; ++i) s = s + J[i][k] * Y[i][c];
+            Bint[k][c] = (k == act[c] ? T(1) : T(0)) - Dinv[k] * s;
+        }
+    }
+    if constexpr (WITH_A) {
+#pragma unroll
+        for (int k = 0; k < NX; ++k)
+#pragma unroll
+            for (int l = 0; l < NX; ++l) {
+                T s = T(0);
+#pragma unroll
+                for (int i = 0; i < NC; ++i) s = s + J[i][k] * Y[i][NA + l];
+                T a = (k == l ? T(1) : T(0)) - Dinv[k] * s;
+#pragma unroll
+                for (int c = 0; c < NA; ++c)
+                    if (act[c] == l) a = a - Bint[k][c];
+                Aint[k][l] = a;
+            }
+    }
+}
+
+// One step of contact model M (its `assemble` builds the QP in the internal coordinate order).
+template <class M, typename S>
+IRS_HD void irs_contact_step(const ModelParams& p, const S* x_ext, const S* u, S* xn_ext) {
+    using T = typename scalar_of<S>::type;
+    constexpr int NX = M::NX, NC = M::NC;
+    S q[NX], qn[NX], b[NX], J[NC][NX], phi[NC];
+    T Dinv[NX];
+    const int iters = M::template assemble<S>(p, x_ext, u, q, Dinv, b, J, phi);
+    irs_contact_qp_step<S, NX, NC>(q, Dinv, b, J, phi, iters, qn);
+#pragma unroll
+    for (int k = 0; k < NX; ++k) xn_ext[M::perm(k)] = qn[k];
+}
+
+// The step and its active-set derivative in the reference's x order: Bext (NX x NU, row-major) and,
+// WITH_A, Aext (NX x NX).
+template <class M, typename T, bool WITH_A>
+IRS_HD void irs_contact_step_grad(const ModelParams& p, const T* x_ext, const T* u, T* xn_ext, T* Bext, T* Aext) {
+    constexpr int NX = M::NX, NC = M::NC, NU = M::NU;
+    T q[NX], qn[NX], b[NX], J[NC][NX], phi[NC], Dinv[NX], W[NC][NC], lam[NC];
+    const int iters = M::template assemble<T>(p, x_ext, u, q, Dinv, b, J, phi);
+    irs_contact_qp_dual<T, NX, NC>(Dinv, b, J, phi, iters, W, lam);
+    irs_contact_qp_primal<T, NX, NC>(q, Dinv, b, J, lam, qn);
+#pragma unroll
+    for (int k = 0; k < NX; ++k) xn_ext[M::perm(k)] = qn[k];
+    int act[NU];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) act[j] = M::act(j);
+    T Bint[NX][NU], Aint[WITH_A ? NX : 1][NX];
+    irs_contact_qp_grad<T, NX, NC, NU, WITH_A>(Dinv, J, W, lam, act, Bint, Aint);
+#pragma unroll
+    for (int k = 0; k < NX; ++k)
+#pragma unroll
+        for (int j = 0; j < NU; ++j) Bext[M::perm(k) * NU + j] = Bint[k][j];
+    if constexpr (WITH_A) {
+#pragma unroll
+        for (int k = 0; k < NX; ++k)
+#pragma unroll
+            for (int l = 0; l < NX; ++l) Aext[M::perm(k) * NX + M::perm(l)] = Aint[k][l];
     }
 }
 
@@ -119,19 +264,27 @@ IRS_HD void irs_contact_qp_step(const S* q, const typename scalar_of<S>::type* D
 struct PlanarHandModel {
     static constexpr int NX = 7, NU = 4, NPARAMS = 12;
     static constexpr int NC = 8;                 // 4 link-disc pairs x 2 friction generators
-    // no differentiable step here: ZERO_ORDER_B returns the decoupled (A,B) of
-    // IrsLqrQuasistatic.decouple_AB_matrices (irs_lqr_quasistatic.py:275-284) -- every contact
+    // not differentiable by dual numbers (HAS_JACOBIAN = false): its Jacobian is the active-set
+    // derivative of the step QP (irs_contact_qp_grad); the sample-pass modes return the decoupled (A,B)
+    // of IrsLqrQuasistatic.decouple_AB_matrices (irs_lqr_quasistatic.py:275-284) -- every contact
     // example sets decouple_AB = True, which discards the sampled A anyway
     static constexpr bool HAS_JACOBIAN = false;
     IRS_HD static constexpr int perm(int k) {       // internal index k -> index in the reference's x
         return k == 0 ? 0 : k == 1 ? 3 : k == 2 ? 6 : k == 3 ? 1 : k == 4 ? 4 : k == 5 ? 2 : 5;
     }
-    IRS_HD static int u_into_x(int j) { return perm(3 + j); }
+    IRS_HD static constexpr int act(int j) { return 3 + j; }      // internal index of the j-th actuated dof
+    IRS_HD static int u_into_x(int j) { return perm(act(j)); }
 
     template <typename S>
     IRS_HD static void step(const ModelParams& p, const S* x_ext, const S* u, S* xn_ext) {
+        irs_contact_step<PlanarHandModel, S>(p, x_ext, u, xn_ext);
+    }
+
+    // the step QP in the internal order: q, D^-1, b, J, phi; returns the PGS sweep count
+    template <typename S>
+    IRS_HD static int assemble(const ModelParams& p, const S* x_ext, const S* u, S* q,
+                               typename scalar_of<S>::type* Dinv, S* b, S (*J)[NX], S* phi) {
         using T = typename scalar_of<S>::type;
-        S q[NX], qn[NX];
 #pragma unroll
         for (int k = 0; k < NX; ++k) q[k] = x_ext[perm(k)];
         const T h = T(p.v[0]), g = T(p.v[1]), mass = T(p.v[2]), R = T(p.v[3]), mu = T(p.v[4]);
@@ -139,10 +292,8 @@ struct PlanarHandModel {
         const int iters = (int)p.v[11];
         // diagonal QP Hessian D and linear term b
         const T inertia = T(0.5) * mass * R * R;
-        T Dinv[NX];
         Dinv[0] = h * h / mass; Dinv[1] = h * h / mass; Dinv[2] = h * h / inertia;
         Dinv[3] = T(1) / kp1; Dinv[4] = T(1) / kp2; Dinv[5] = T(1) / kp1; Dinv[6] = T(1) / kp2;
-        S b[NX];
         b[0] = q[0] * T(0);
         b[1] = q[1] * T(0) + mass * g;           // -tau_u, tau_u = (0, -m g, 0)
         b[2] = q[2] * T(0);
@@ -150,7 +301,6 @@ struct PlanarHandModel {
         b[5] = kp1 * (q[5] - u[2]); b[6] = kp2 * (q[6] - u[3]);
 
         // contact rows: J (NC x NX), phi (NC)
-        S J[NC][NX], phi[NC];
 #pragma unroll
         for (int arm = 0; arm < 2; ++arm) {
             const T base = arm == 0 ? -bx : bx;
@@ -203,9 +353,7 @@ struct PlanarHandModel {
                 }
             }
         }
-        irs_contact_qp_step<S, NX, NC>(q, Dinv, b, J, phi, iters, qn);
-#pragma unroll
-        for (int k = 0; k < NX; ++k) xn_ext[perm(k)] = qn[k];
+        return iters;
     }
 };
 
@@ -272,26 +420,29 @@ struct BoxPivotModel {
     static constexpr int NC = 12;
     static constexpr bool HAS_JACOBIAN = false;
     IRS_HD static constexpr int perm(int k) { return k == 0 ? 1 : k == 1 ? 3 : k == 2 ? 4 : k == 3 ? 0 : 2; }
-    IRS_HD static int u_into_x(int j) { return perm(3 + j); }
+    IRS_HD static constexpr int act(int j) { return 3 + j; }
+    IRS_HD static int u_into_x(int j) { return perm(act(j)); }
 
     template <typename S>
     IRS_HD static void step(const ModelParams& p, const S* x_ext, const S* u, S* xn_ext) {
+        irs_contact_step<BoxPivotModel, S>(p, x_ext, u, xn_ext);
+    }
+
+    template <typename S>
+    IRS_HD static int assemble(const ModelParams& p, const S* x_ext, const S* u, S* q,
+                               typename scalar_of<S>::type* Dinv, S* b, S (*J)[NX], S* phi) {
         using T = typename scalar_of<S>::type;
         const T h = T(p.v[0]), g = T(p.v[1]), mass = T(p.v[2]), a = T(p.v[3]), mu = T(p.v[4]);
         const T kp = T(p.v[5]), rh = T(p.v[6]);
         const int iters = (int)p.v[7];
-        S q[NX], qn[NX];
 #pragma unroll
         for (int k = 0; k < NX; ++k) q[k] = x_ext[perm(k)];
         const T inertia = mass * (T(2) * a) * (T(2) * a) / T(6);     // square plate, side 2a
-        T Dinv[NX];
         Dinv[0] = h * h / mass; Dinv[1] = h * h / mass; Dinv[2] = h * h / inertia;
         Dinv[3] = T(1) / kp; Dinv[4] = T(1) / kp;
-        S b[NX];
         b[0] = S(T(0)); b[1] = S(mass * g); b[2] = S(T(0));
         b[3] = kp * (q[3] - u[0]); b[4] = kp * (q[4] - u[1]);
 
-        S J[NC][NX], phi[NC];
         S sn, cs;
         irs_sincos(q[2], sn, cs);
         // rows 0..7: box corners (+-a, +-a) against the ground
@@ -324,9 +475,7 @@ struct BoxPivotModel {
             J[row][3] = S(sg);
             J[row][4] = S(T(1));
         }
-        irs_contact_qp_step<S, NX, NC>(q, Dinv, b, J, phi, iters, qn);
-#pragma unroll
-        for (int k = 0; k < NX; ++k) xn_ext[perm(k)] = qn[k];
+        return iters;
     }
 };
 
@@ -340,32 +489,38 @@ struct BoxOnBoxModel {
     static constexpr int NX = 2, NU = 1, NPARAMS = 4;
     static constexpr int NC = 2;
     static constexpr bool HAS_JACOBIAN = false;
+    IRS_HD static constexpr int perm(int k) { return k; }
+    IRS_HD static constexpr int act(int) { return 0; }
     IRS_HD static int u_into_x(int) { return 0; }
 
     template <typename S>
-    IRS_HD static void step(const ModelParams& p, const S* q, const S* u, S* qn) {
+    IRS_HD static void step(const ModelParams& p, const S* x, const S* u, S* xn) {
+        irs_contact_step<BoxOnBoxModel, S>(p, x, u, xn);
+    }
+
+    template <typename S>
+    IRS_HD static int assemble(const ModelParams& p, const S* x, const S* u, S* q,
+                               typename scalar_of<S>::type* Dinv, S* b, S (*J)[NX], S* phi) {
         using T = typename scalar_of<S>::type;
         const T h = T(p.v[0]), m = T(p.v[1]), k = T(p.v[2]);
-        const int iters = (int)p.v[3];
-        T Dinv[NX];
+        q[0] = x[0]; q[1] = x[1];
         Dinv[0] = T(1) / k; Dinv[1] = h * h / m;
-        S b[NX];
         b[0] = k * (q[0] - u[0]);
         b[1] = q[1] * T(0);
-        S J[NC][NX], phi[NC];
 #pragma unroll
         for (int r = 0; r < NC; ++r) {
             J[r][0] = S(T(-1)); J[r][1] = S(T(1));
             phi[r] = q[1] - q[0];
         }
-        irs_contact_qp_step<S, NX, NC>(q, Dinv, b, J, phi, iters, qn);
+        return (int)p.v[3];
     }
 };
 
 // examples/box_pushing (box_pushing_setup.py:6-19): the same box and disc seen from above -- no gravity,
 // no ground, Kp = 500.  PINNED by the simulator data the reference ships,
 // examples/box_pushing/analysis/{xu,dxdu}_quasistatic.npy (tests/golden/box_pushing_*.npy): the 80-step
-// push and the simulator's input Jacobians; they identify mass = 5, inertia = 1/6, r_hand = 0.0995.
+// push and the simulator's Jacobians; they identify mass = 5, inertia = 1/6, half side 0.4995, r_hand = 0.1
+// (the host passes them: irs_mpc_amd/systems.py).
 //   x = [x_h, x_b, y_h, y_b, th_b], u = commanded hand position
 //   params = {h, mass, inertia, half, mu, kp, r_hand, pgs_iters}
 struct BoxPushModel {
@@ -373,29 +528,29 @@ struct BoxPushModel {
     static constexpr int NC = 2;
     static constexpr bool HAS_JACOBIAN = false;
     IRS_HD static constexpr int perm(int k) { return BoxPivotModel::perm(k); }
-    IRS_HD static int u_into_x(int j) { return perm(3 + j); }
+    IRS_HD static constexpr int act(int j) { return 3 + j; }
+    IRS_HD static int u_into_x(int j) { return perm(act(j)); }
 
     template <typename S>
     IRS_HD static void step(const ModelParams& p, const S* x_ext, const S* u, S* xn_ext) {
+        irs_contact_step<BoxPushModel, S>(p, x_ext, u, xn_ext);
+    }
+
+    template <typename S>
+    IRS_HD static int assemble(const ModelParams& p, const S* x_ext, const S* u, S* q,
+                               typename scalar_of<S>::type* Dinv, S* b, S (*J)[NX], S* phi) {
         using T = typename scalar_of<S>::type;
         const T h = T(p.v[0]), mass = T(p.v[1]), inertia = T(p.v[2]), a = T(p.v[3]), mu = T(p.v[4]);
         const T kp = T(p.v[5]), rh = T(p.v[6]);
-        const int iters = (int)p.v[7];
-        S q[NX], qn[NX];
 #pragma unroll
         for (int k = 0; k < NX; ++k) q[k] = x_ext[perm(k)];
-        T Dinv[NX];
         Dinv[0] = h * h / mass; Dinv[1] = h * h / mass; Dinv[2] = h * h / inertia;
         Dinv[3] = T(1) / kp; Dinv[4] = T(1) / kp;
-        S b[NX];
         b[0] = S(T(0)); b[1] = S(T(0)); b[2] = S(T(0));
         b[3] = kp * (q[3] - u[0]); b[4] = kp * (q[4] - u[1]);
-        S J[NC][NX], phi[NC];
         S sn, cs;
         irs_sincos(q[2], sn, cs);
         irs_hand_box_rows<S, T>(q, sn, cs, a, rh, mu, J, phi, 0);
-        irs_contact_qp_step<S, NX, NC>(q, Dinv, b, J, phi, iters, qn);
-#pragma unroll
-        for (int k = 0; k < NX; ++k) xn_ext[perm(k)] = qn[k];
+        return (int)p.v[7];
     }
 };

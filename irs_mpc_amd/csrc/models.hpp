@@ -146,21 +146,36 @@ struct ThreeCartModel {
 
 #include "contact_models.hpp"
 
-// J (n x (n+m), row-major) = d step / d [x,u] at (x,u), T = float or double.
+// J (n x (n+m), row-major) = d step / d [x,u] at (x,u), T = float or double.  Analytic models are
+// differentiated by dual numbers (the reference: symbolic / forward-mode AD,
+// examples/quadrotor/quadrotor_dynamics.py:136-138); contact models through the active constraints of
+// their step QP (the reference: q_sim.get_Dq_nextDq / get_Dq_nextDqa_cmd, quasistatic_dynamics.py:184-191).
 template <class Model, typename T>
 IRS_HD void model_jacobian(const ModelParams& p, const T* x, const T* u, T* xn, T* J) {
     constexpr int n = Model::NX, m = Model::NU, d = n + m;
-    using D = Dual<T, d>;
-    D xd[n], ud[m], out[n];
+    if constexpr (Model::HAS_JACOBIAN) {
+        using D = Dual<T, d>;
+        D xd[n], ud[m], out[n];
 #pragma unroll
-    for (int i = 0; i < n; ++i) xd[i] = make_var<T, d>(x[i], i);
+        for (int i = 0; i < n; ++i) xd[i] = make_var<T, d>(x[i], i);
 #pragma unroll
-    for (int j = 0; j < m; ++j) ud[j] = make_var<T, d>(u[j], n + j);
-    Model::template step<D>(p, xd, ud, out);
+        for (int j = 0; j < m; ++j) ud[j] = make_var<T, d>(u[j], n + j);
+        Model::template step<D>(p, xd, ud, out);
 #pragma unroll
-    for (int i = 0; i < n; ++i) {
-        xn[i] = out[i].v;
+        for (int i = 0; i < n; ++i) {
+            xn[i] = out[i].v;
 #pragma unroll
-        for (int j = 0; j < d; ++j) J[i * d + j] = out[i].d[j];
+            for (int j = 0; j < d; ++j) J[i * d + j] = out[i].d[j];
+        }
+    } else {
+        T A[n * n], B[n * m];
+        irs_contact_step_grad<Model, T, true>(p, x, u, xn, B, A);
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+#pragma unroll
+            for (int k = 0; k < n; ++k) J[i * d + k] = A[i * n + k];
+#pragma unroll
+            for (int k = 0; k < m; ++k) J[i * d + n + k] = B[i * m + k];
+        }
     }
 }

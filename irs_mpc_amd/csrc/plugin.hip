@@ -41,8 +41,7 @@ __global__ __launch_bounds__(64) void jacobian_batch_kernel(ModelParams p, const
     for (int i = 0; i < n; ++i) x[i] = X[(size_t)b * n + i];
 #pragma unroll
     for (int j = 0; j < m; ++j) u[j] = U[(size_t)b * m + j];
-    if constexpr (!Model::HAS_JACOBIAN) return;
-    else model_jacobian<Model, double>(p, x, u, xn, Jl);
+    model_jacobian<Model, double>(p, x, u, xn, Jl);
 #pragma unroll
     for (int q = 0; q < n * d; ++q) J[(size_t)b * n * d + q] = Jl[q];
 }
@@ -86,10 +85,6 @@ int irs_jacobian_xu_batch(int model, const double* params, int n_params, const d
     if (rc != IRS_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     IRS_DISPATCH_MODEL(model, {
-        if (!Model::HAS_JACOBIAN) {
-            irs_set_error("irs_jacobian_xu_batch: model %d has no differentiable step", model);
-            return IRS_ERR_UNSUPPORTED;
-        }
         hipLaunchKernelGGL((jacobian_batch_kernel<Model>), dim3((B + 63) / 64), dim3(64), 0, st, p, X, U, B, J);
     });
     IRS_CHECK_LAUNCH();

@@ -42,7 +42,7 @@ constexpr size_t fnom_bytes(int T) { return (size_t)T * 32 * sizeof(double); }
 // 0 of every timestep takes fewer samples and evaluates the f64 nominal step the solve needs while
 // the other workgroups are still sampling, instead of the last arriver doing it serially
 template <class Model, int MODE>
-constexpr bool nominal_in_wg0() { return !Model::HAS_JACOBIAN && MODE != IRS_SMOOTH_FIRST_ORDER; }
+constexpr bool nominal_in_wg0() { return !Model::HAS_JACOBIAN; }
 constexpr int kNominalCost = 3;      // the f64 nominal step costs about this many f32 sample evaluations
 
 template <class Model, int MODE>
@@ -50,7 +50,8 @@ struct SmoothTraits {
     static constexpr int n = Model::NX, m = Model::NU, d = n + m;
     // perturbed components that enter the least-squares design matrix
     static constexpr int NZ = (MODE == IRS_SMOOTH_ZERO_ORDER_B) ? m : d;
-    static constexpr int Z0 = (MODE == IRS_SMOOTH_ZERO_ORDER_B) ? n : 0;  // first one
+    // first perturbed component: n when only u is perturbed (ZERO_ORDER_B; FIRST_ORDER of a contact model)
+    static constexpr int Z0 = (MODE == IRS_SMOOTH_ZERO_ORDER_B || (MODE == IRS_SMOOTH_FIRST_ORDER && !Model::HAS_JACOBIAN)) ? n : 0;
     static constexpr int NG = NZ * (NZ + 1) / 2;
     // zero-order statistics: upper Gram of z and z df'.  Models with an expensive step (contact QPs)
     // take df = f(x+dx,u+du) - xb and append sum(z): the solve then subtracts the nominal step,
@@ -59,7 +60,12 @@ struct SmoothTraits {
     // the three extra accumulators cost more than the nominal evaluation (measured, pendulum).
     static constexpr bool SUMZ = MODE != IRS_SMOOTH_FIRST_ORDER && !Model::HAS_JACOBIAN;
     static constexpr int NH = NG + NZ * n;     // offset of the sum-of-z block
-    static constexpr int P = (MODE == IRS_SMOOTH_FIRST_ORDER) ? n * d : NG + NZ * n + (SUMZ ? NZ : 0);
+    // first-order statistics: the sum of the sampled Jacobians [A | B] (n x d).  Contact models perturb
+    // u only (calc_AB_first_order, quasistatic_dynamics.py:193-208) and return the decoupled pair like
+    // ZERO_ORDER_B, so only the n x m block B of the active-set derivative is summed
+    static constexpr bool FIRST_B = MODE == IRS_SMOOTH_FIRST_ORDER && !Model::HAS_JACOBIAN;
+    static constexpr int P = FIRST_B ? n * m
+                             : (MODE == IRS_SMOOTH_FIRST_ORDER) ? n * d : NG + NZ * n + (SUMZ ? NZ : 0);
     static constexpr int PP = irs_reduce_pad(P);
     // last-arriver reduction: NGRP groups of P lanes each sum a strided subset of blocks
     static constexpr int NGRP = (P >= kBlock) ? 1 : kBlock / P;
@@ -171,7 +177,17 @@ __device__ __forceinline__ void finalize_timestep(const ModelParams& p, const do
     for (int j = 0; j < m; ++j) u[j] = u_trj[(size_t)t * m + j];
 
     if (lane == 0) L.bad = 0;
-    if constexpr (MODE == IRS_SMOOTH_FIRST_ORDER) {
+    if constexpr (TR::FIRST_B) {
+        // mean of the sampled B, inside the decoupled structure (irs_lqr_quasistatic.py:275-284)
+        nominal(x, u, f);
+        for (int q = lane; q < n * n; q += 64) {
+            int i = q / n, k = q % n;
+            bool act = false;
+            for (int j = 0; j < m; ++j) act = act || (Model::u_into_x(j) == k);
+            L.AB[i][k] = (i == k && !act) ? 1.0 : 0.0;
+        }
+        for (int q = lane; q < n * m; q += 64) L.AB[q / m][n + q % m] = S[q] / n_total;
+    } else if constexpr (MODE == IRS_SMOOTH_FIRST_ORDER) {
         Model::template step<double>(p, x, u, f);
         for (int q = lane; q < n * d; q += 64) L.AB[q / d][q % d] = S[q] / n_total;
     } else {
@@ -341,7 +357,7 @@ __device__ __forceinline__ void finalize_timestep(const ModelParams& p, const do
         }  // NZ > 4
     }
     wave_sync();
-    if constexpr (MODE == IRS_SMOOTH_ZERO_ORDER_B && !Model::HAS_JACOBIAN) {
+    if constexpr ((MODE == IRS_SMOOTH_ZERO_ORDER_B && !Model::HAS_JACOBIAN) || TR::FIRST_B) {
         for (int q = lane; q < m * m; q += 64) L.AB[Model::u_into_x(q / m)][n + q % m] = (q / m == q % m) ? 1.0 : 0.0;
         wave_sync();
     }
@@ -520,7 +536,12 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
 #pragma unroll
                 for (int j = 0; j < m; ++j) us[j] = ub[j] + z[n + j];
 
-                if constexpr (MODE == IRS_SMOOTH_FIRST_ORDER) {
+                if constexpr (TR::FIRST_B) {
+                    float Bs[n * m];
+                    irs_contact_step_grad<Model, float, false>(a.p, xs, us, fx, Bs, nullptr);
+#pragma unroll
+                    for (int q = 0; q < n * m; ++q) acc[q] += Bs[q];
+                } else if constexpr (MODE == IRS_SMOOTH_FIRST_ORDER) {
                     float J[n * d];
                     model_jacobian<Model, float>(a.p, xs, us, fx, J);
                     const float w = (U == 1 || valid[uu]) ? 1.f : 0.f;
@@ -675,8 +696,7 @@ __global__ __launch_bounds__(64) void exact_linearize_kernel(ModelParams p, cons
     for (int i = 0; i < n; ++i) x[i] = x_trj[(size_t)t * n + i];
 #pragma unroll
     for (int j = 0; j < m; ++j) u[j] = u_trj[(size_t)t * m + j];
-    if constexpr (!Model::HAS_JACOBIAN) return;
-    else model_jacobian<Model, double>(p, x, u, f, J);
+    model_jacobian<Model, double>(p, x, u, f, J);
 #pragma unroll
     for (int i = 0; i < n; ++i) {
         double c = f[i];
@@ -794,7 +814,8 @@ bool is_light(int model, int mode) {
 
 bool has_nominal_in_wg0(int model, int mode) {
     bool r = false;
-    IRS_DISPATCH_MODEL(model, { r = !Model::HAS_JACOBIAN && mode != IRS_SMOOTH_FIRST_ORDER; });
+    (void)mode;
+    IRS_DISPATCH_MODEL(model, { r = !Model::HAS_JACOBIAN; });
     return r;
 }
 
@@ -832,10 +853,7 @@ template <class Model>
 int launch_smooth(int mode, const SmoothArgs& a, bool rng, bool fuse, hipStream_t st) {
     switch (mode) {
         case IRS_SMOOTH_ZERO_ORDER_AB: launch_smooth_m<Model, IRS_SMOOTH_ZERO_ORDER_AB>(a, rng, fuse, st); break;
-        case IRS_SMOOTH_FIRST_ORDER:
-            if constexpr (Model::HAS_JACOBIAN) launch_smooth_m<Model, IRS_SMOOTH_FIRST_ORDER>(a, rng, fuse, st);
-            else return IRS_ERR_UNSUPPORTED;
-            break;
+        case IRS_SMOOTH_FIRST_ORDER: launch_smooth_m<Model, IRS_SMOOTH_FIRST_ORDER>(a, rng, fuse, st); break;
         case IRS_SMOOTH_ZERO_ORDER_B: launch_smooth_m<Model, IRS_SMOOTH_ZERO_ORDER_B>(a, rng, fuse, st); break;
         default: return IRS_ERR_UNSUPPORTED;
     }
@@ -850,9 +868,7 @@ int launch_finalize(int mode, const SmoothArgs& a, hipStream_t st) {
             hipLaunchKernelGGL((smooth_finalize_kernel<Model, IRS_SMOOTH_ZERO_ORDER_AB>), grid, block, 0, st, a);
             break;
         case IRS_SMOOTH_FIRST_ORDER:
-            if constexpr (Model::HAS_JACOBIAN)
-                hipLaunchKernelGGL((smooth_finalize_kernel<Model, IRS_SMOOTH_FIRST_ORDER>), grid, block, 0, st, a);
-            else return IRS_ERR_UNSUPPORTED;
+            hipLaunchKernelGGL((smooth_finalize_kernel<Model, IRS_SMOOTH_FIRST_ORDER>), grid, block, 0, st, a);
             break;
         case IRS_SMOOTH_ZERO_ORDER_B:
             hipLaunchKernelGGL((smooth_finalize_kernel<Model, IRS_SMOOTH_ZERO_ORDER_B>), grid, block, 0, st, a);
@@ -907,22 +923,24 @@ int smooth_common(int model, const double* params, int n_params, int mode, int T
         a.n_total = (double)out->n_total;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    IRS_DISPATCH_MODEL(model, {
-        if (!Model::HAS_JACOBIAN && mode == IRS_SMOOTH_FIRST_ORDER) {
-            irs_set_error("irs_smooth: model %d has no differentiable step (FIRST_ORDER unsupported)", model);
-            return IRS_ERR_UNSUPPORTED;
-        }
-        rc = launch_smooth<Model>(mode, a, rng, fuse, st);
-    });
+    IRS_DISPATCH_MODEL(model, { rc = launch_smooth<Model>(mode, a, rng, fuse, st); });
     if (rc != IRS_OK) return rc;
     IRS_CHECK_LAUNCH();
     return IRS_OK;
 }
 
+// modes that perturb u only never read dx / std_x
+bool u_noise_only(int model, int mode) {
+    if (mode == IRS_SMOOTH_ZERO_ORDER_B) return true;
+    bool contact = false;
+    IRS_DISPATCH_MODEL(model, { contact = !Model::HAS_JACOBIAN; });
+    return contact && mode == IRS_SMOOTH_FIRST_ORDER;
+}
+
 int fill_rng(int model, int mode, const double* std_x, const double* std_u, uint64_t seed, uint32_t iter,
              uint64_t sample_offset, SmoothArgs& a) {
     IRS_CHECK_ARG(std_u != nullptr, "std_u is null");
-    IRS_CHECK_ARG(std_x != nullptr || mode == IRS_SMOOTH_ZERO_ORDER_B, "std_x is null");
+    IRS_CHECK_ARG(std_x != nullptr || u_noise_only(model, mode), "std_x is null");
     int n, m, np;
     int rc = irs_model_info(model, &n, &m, &np);
     if (rc != IRS_OK) return rc;
@@ -932,9 +950,9 @@ int fill_rng(int model, int mode, const double* std_x, const double* std_u, uint
     return IRS_OK;
 }
 
-int check_samples(const float* dx, const float* du, int mode) {
+int check_samples(const float* dx, const float* du, int model, int mode) {
     IRS_CHECK_ARG(du != nullptr, "du is null");
-    IRS_CHECK_ARG(dx != nullptr || mode == IRS_SMOOTH_ZERO_ORDER_B, "dx is null");
+    IRS_CHECK_ARG(dx != nullptr || u_noise_only(model, mode), "dx is null");
     IRS_CHECK_ARG((reinterpret_cast<uintptr_t>(dx) & 15) == 0 && (reinterpret_cast<uintptr_t>(du) & 15) == 0,
                   "dx/du must be 16-byte aligned");
     return IRS_OK;
@@ -970,7 +988,7 @@ int irs_smooth_accumulate(int model, const double* params, int n_params, int mod
                           const double* x_trj, const double* u_trj, const float* dx,
                           const float* du, double* sums, void* workspace,
                           size_t workspace_bytes, void* stream) {
-    int rc = check_samples(dx, du, mode);
+    int rc = check_samples(dx, du, model, mode);
     if (rc != IRS_OK) return rc;
     SmoothArgs a;
     memset(&a, 0, sizeof(a));
@@ -996,7 +1014,7 @@ int irs_smooth(int model, const double* params, int n_params, int mode, int T, i
                const double* x_trj, const double* u_trj, const float* dx, const float* du,
                double* sums, double* At, double* Bt, double* ct, int* info, void* workspace,
                size_t workspace_bytes, void* stream) {
-    int rc = check_samples(dx, du, mode);
+    int rc = check_samples(dx, du, model, mode);
     if (rc != IRS_OK) return rc;
     SmoothArgs a;
     memset(&a, 0, sizeof(a));
@@ -1027,7 +1045,7 @@ int irs_smooth_run(const irs_smooth_call* c, void* stream) {
     if (c->use_rng) {
         rc = fill_rng(c->model, c->mode, c->std_x, c->std_u, c->seed, c->iter, c->sample_offset, a);
     } else {
-        rc = check_samples(c->dx, c->du, c->mode);
+        rc = check_samples(c->dx, c->du, c->model, c->mode);
         a.dx = c->dx; a.du = c->du;
     }
     if (rc != IRS_OK) return rc;
@@ -1099,10 +1117,6 @@ int irs_exact_linearize(int model, const double* params, int n_params, int T, co
     if (rc != IRS_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     IRS_DISPATCH_MODEL(model, {
-        if (!Model::HAS_JACOBIAN) {
-            irs_set_error("irs_exact_linearize: model %d has no differentiable step", model);
-            return IRS_ERR_UNSUPPORTED;
-        }
         hipLaunchKernelGGL((exact_linearize_kernel<Model>), dim3((T + 63) / 64), dim3(64), 0, st, p,
                            x_trj, u_trj, At, Bt, ct, T);
     });

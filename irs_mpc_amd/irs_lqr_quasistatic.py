@@ -15,9 +15,12 @@ underneath:
   * `local_descent`'s T re-solved, bounded QPs (solve_tvlqr + Gurobi, :326-345) run in one launch
     (csrc/boxqp.hip, ADMM around a shared Riccati factorisation of the [x; u_prev] problem).
   * `q_dynamics` is a device-backed functor (e.g. PlanarHandDynamics), not the external
-    quasistatic_simulator; gradient modes that need the simulator's analytic derivatives
-    ("first_order", "exact", and any mode without decouple_AB) raise NotImplementedError;
-    "zero_order_B" and "zero_order_AB" (the damped joint fit of calc_AB_zero_order) run.
+    quasistatic_simulator.  All four gradient modes run: "zero_order_B", "zero_order_AB" (the damped
+    joint fit of calc_AB_zero_order), "first_order" (the mean over the u-perturbed samples of the
+    step's active-set derivative -- the simulator's Dq_nextDqa_cmd -- computed per sample inside the
+    sample pass) and "exact" (that derivative at the nominal point).  The sample-pass modes return
+    the decoupled pair, so they need decouple_AB = True (every example of the reference sets it);
+    "exact" also runs with decouple_AB = False (full [Dq_nextDq | Dq_nextDqa_cmd]).
 
 `params.sampling(std_u_initial, iter)` returns the std of the u-perturbations like the reference;
 the draws are made on the host by `np.random.normal(0, std_u, (num_samples, dim_u))` once per
@@ -30,7 +33,7 @@ import torch
 
 from . import device as dev
 from . import distributed as dist_util
-from ._lib import SMOOTH_ZERO_ORDER_AB, SMOOTH_ZERO_ORDER_B
+from ._lib import SMOOTH_FIRST_ORDER, SMOOTH_ZERO_ORDER_AB, SMOOTH_ZERO_ORDER_B
 from .quasistatic_base import QuasistaticOptimizerBase, quasistatic_eval_cost  # noqa: F401
 from .tv_lqr import get_solver
 
@@ -81,11 +84,13 @@ class IrsLqrQuasistatic(QuasistaticOptimizerBase):
         for name in ("x_bounds_abs", "u_bounds_abs", "x_bounds_rel", "u_bounds_rel", "decouple_AB", "use_workers",
                      "gradient_mode", "task_stride", "std_u_initial", "sampling", "num_samples"):
             setattr(self, name, getattr(params, name))
-        if self.gradient_mode not in ("zero_order_B", "zero_order_AB") or not self.decouple_AB:
+        if self.gradient_mode not in ("zero_order_B", "zero_order_AB", "first_order", "exact"):
+            raise RuntimeError(f"AB mode {self.gradient_mode} is not supported.")   # quasistatic_dynamics.py:238
+        if self.gradient_mode != "exact" and not self.decouple_AB:
             raise NotImplementedError(
-                "gradient_mode=%r with decouple_AB=%r needs the quasistatic simulator's analytic "
-                "derivatives (q_sim.get_Dq_nextDq); the device functors provide zero_order_B and "
-                "zero_order_AB with decouple_AB=True" % (self.gradient_mode, self.decouple_AB))
+                "gradient_mode=%r with decouple_AB=False: the device sample pass returns the decoupled "
+                "(A, B) of irs_lqr_quasistatic.py:275-284 (every example of the reference sets "
+                "decouple_AB=True); only \"exact\" keeps the full Jacobian" % (self.gradient_mode,))
         if self.x_bounds_rel is not None:
             raise NotImplementedError("x_bounds_rel ('should be rarely used', irs_lqr_quasistatic.py:315) "
                                       "is not implemented on the device")
@@ -107,6 +112,10 @@ class IrsLqrQuasistatic(QuasistaticOptimizerBase):
                                 (self.dim_u,))
         if self.gradient_mode == "zero_order_AB":
             return self._zero_order_AB_dev(x_trj, u_trj, std_u)
+        if self.gradient_mode == "exact":
+            return self._exact_dev(x_trj, u_trj)
+        # "zero_order_B": least-squares fit of B; "first_order": mean of the per-sample derivative
+        MODE = SMOOTH_FIRST_ORDER if self.gradient_mode == "first_order" else SMOOTH_ZERO_ORDER_B
         rank, world = dist_util.rank_world()
         N = self.num_samples
         seed = getattr(self.params, "device_rng_seed", None)
@@ -117,22 +126,36 @@ class IrsLqrQuasistatic(QuasistaticOptimizerBase):
             du = dev.to_dev(np.ascontiguousarray(du[:, lo:hi], np.float32), dev.F32)
         if world == 1:
             if seed is None:
-                o = self._dm.smooth(SMOOTH_ZERO_ORDER_B, x_trj, u_trj, None, du)
+                o = self._dm.smooth(MODE, x_trj, u_trj, None, du)
             else:
-                o = self._dm.smooth_rng(SMOOTH_ZERO_ORDER_B, x_trj, u_trj, N, None, std_u, int(seed),
+                o = self._dm.smooth_rng(MODE, x_trj, u_trj, N, None, std_u, int(seed),
                                         self.current_iter)
             self._smooth_info = o["info"]
             return o["At"], o["Bt"], o["ct"]
         if seed is None:
-            sums = self._dm.smooth_accumulate(SMOOTH_ZERO_ORDER_B, x_trj, u_trj, None, du)
+            sums = self._dm.smooth_accumulate(MODE, x_trj, u_trj, None, du)
         else:
-            sums = self._dm.smooth_accumulate_rng(SMOOTH_ZERO_ORDER_B, x_trj, u_trj, hi - lo, None, std_u,
+            sums = self._dm.smooth_accumulate_rng(MODE, x_trj, u_trj, hi - lo, None, std_u,
                                                   int(seed), self.current_iter, sample_offset=lo)
         dist_util.all_reduce_sums(sums)
         # the accumulate launch left the f64 nominal contact steps in its workspace: reuse them
-        ws = self._dm._workspace(SMOOTH_ZERO_ORDER_B, self.T, hi - lo, x_trj.device)
-        At, Bt, ct, info = self._dm.smooth_finalize(SMOOTH_ZERO_ORDER_B, N, x_trj, u_trj, sums, workspace=ws)
+        ws = self._dm._workspace(MODE, self.T, hi - lo, x_trj.device)
+        At, Bt, ct, info = self._dm.smooth_finalize(MODE, N, x_trj, u_trj, sums, workspace=ws)
         self._smooth_info = info
+        return At, Bt, ct
+
+    def _exact_dev(self, x_trj, u_trj):
+        """gradient_mode "exact" (calc_AB_exact, quasistatic_dynamics.py:189-191): the step's active-set
+        derivative at the nominal points, one f64 lane per time step; then decouple_AB_matrices if asked
+        and c_t = f - A x - B u (irs_lqr_quasistatic.py:218-225)."""
+        At, Bt, ct = self._dm.exact_linearize(x_trj, u_trj)
+        self._smooth_info = torch.zeros(self.T, dtype=torch.int32, device=x_trj.device)
+        if self.decouple_AB:
+            f = ct + torch.einsum("tij,tj->ti", At, x_trj[:-1]) + torch.einsum("tij,tj->ti", Bt, u_trj)
+            Bt[:, self._idx, :] = torch.eye(self.dim_u, dtype=At.dtype, device=At.device)
+            At[:] = torch.eye(self.dim_x, dtype=At.dtype, device=At.device)
+            At[:, :, self._idx] = 0.0
+            ct = (f - torch.einsum("tij,tj->ti", At, x_trj[:-1]) - torch.einsum("tij,tj->ti", Bt, u_trj)).contiguous()
         return At, Bt, ct
 
     # calc_AB_zero_order's defaults (quasistatic_dynamics.py:268-272)

@@ -72,8 +72,14 @@ class QuasistaticDeviceDynamics(DynamicalSystem):
     """What `QuasistaticDynamics` (irs_lqr/quasistatic_dynamics.py:15-164) offers besides the step:
     the bookkeeping it derives from the plant (:22-28), keyed by model NAME here (the reference keys
     by ModelInstanceIndex).  Subclasses set `models_unactuated`, `models_actuated`,
-    `position_indices` and a device functor without a Jacobian: `jacobian_xu*` raise, `ZERO_ORDER_B`
-    smoothing returns the decoupled (A,B)."""
+    `position_indices` and a device contact functor.  `jacobian_xu*` return the simulator's
+    `[Dq_nextDq | Dq_nextDqa_cmd]` (:184-191): the derivative of the step QP through its active
+    constraints, contact geometry held fixed.  The sample-pass modes (`ZERO_ORDER_B`, `FIRST_ORDER`)
+    return the decoupled (A,B) of irs_lqr_quasistatic.py:275-284."""
+
+    def calc_AB_exact(self, x_nominal, u_nominal):
+        """quasistatic_dynamics.py:189-191."""
+        return self.jacobian_xu(x_nominal, u_nominal)
 
     def _finish_bookkeeping(self):
         self.models_all = self.models_unactuated + self.models_actuated
@@ -129,8 +135,7 @@ class PlanarHandDynamics(QuasistaticDeviceDynamics):
     2-link arms, x = [xo, ql1, qr1, yo, ql2, qr2, th] (the reference's order), u = commanded joint
     angles [ql1, ql2, qr1, qr2].  Steps the
     Anitescu convex quasi-dynamic QP on the device (csrc/contact_models.hpp); the reference steps
-    the external quasistatic_simulator, so parity for this model is UNPINNED.  No Jacobian:
-    `jacobian_xu*` raise, `ZERO_ORDER_B` smoothing returns the decoupled (A,B)."""
+    the external quasistatic_simulator, so parity for this model is UNPINNED."""
     device_model = MODEL_PLANAR_HAND
 
     def __init__(self, h, mass=1.0, mu=0.5, pgs_iters=50):
@@ -212,8 +217,9 @@ class BoxPushingDynamics(BoxPivotingDynamics):
     """Device twin of `QuasistaticDynamics` for examples/box_pushing (box_pushing_setup.py:6-19,
     run_box_pushing.py:20-75): the box and disc of box_pivoting seen from above -- no gravity, no
     ground, Kp = 500.  x = [x_h, x_b, y_h, y_b, th_b], u = commanded hand position.  PINNED: mass 5,
-    inertia 1/6 and r_hand 0.0995 are identified from -- and the step reproduces to 1e-8 -- the
-    simulator trajectory the reference ships (examples/box_pushing/analysis/xu_quasistatic.npy)."""
+    inertia 1/6, half side 0.4995 and r_hand 0.1 are identified from the simulator data the reference
+    ships (examples/box_pushing/analysis/{xu,dxdu}_quasistatic.npy); the step reproduces the recorded
+    trajectory to 3e-8 and `jacobian_xu` the recorded Jacobians to 5e-7."""
     device_model = MODEL_BOX_PUSH
 
     def __init__(self, h=0.1, mass=5.0, inertia=1.0 / 6.0, mu=0.5, pgs_iters=50):
@@ -221,7 +227,8 @@ class BoxPushingDynamics(BoxPivotingDynamics):
         self.g = 0.0             # box_pushing_setup.py:18
         self.inertia = inertia
         self.kp = 500.0          # box_pushing_setup.py:10
-        self.r_hand = 0.0995
+        self.half = 0.4995       # lever arm of the contact point in the simulator's sticking Jacobians
+        self.r_hand = 0.1        # touching distance 0.5995 in the recorded push
 
     def device_params(self):
         return [self.h, self.mass, self.inertia, self.half, self.mu, self.kp, self.r_hand, float(self.pgs_iters)]

@@ -322,10 +322,83 @@ class _ContactQPOracle:
         out[self.PERM] += (J.T.dot(res.x) - b) * Dinv
         return out
 
-    def jacobian_xu(self, x, u):
-        raise NotImplementedError("no differentiable step; see zero_order_B_decoupled")
+    ACTIVE_TOL = 1e-7       # a contact row is active when lam_i W_ii (a length) exceeds this
+    PIVOT_TOL = 1e-5        # an active row whose pivot falls below PIVOT_TOL * W_ii is dependent: dropped
 
-    jacobian_xu_batch = jacobian_xu
+    def _pgs(self, x, u):
+        Dinv, b, J, phi = self._qp(x, u)
+        nc = J.shape[1]
+        W = np.einsum("bik,k,bjk->bij", J, Dinv, J)
+        r = phi - np.einsum("bik,k,bk->bi", J, Dinv, b)
+        lam = np.zeros_like(r)
+        invW = 1.0 / np.einsum("bii->bi", W)
+        g = r.copy()
+        for _ in range(int(self.pgs_iters)):
+            for i in range(nc):
+                new = np.maximum(lam[:, i] - g[:, i] * invW[:, i], 0.0)
+                g += W[:, :, i] * (new - lam[:, i])[:, None]
+                lam[:, i] = new
+        return Dinv, b, J, W, lam
+
+    def jacobian_xu_batch(self, x, u):
+        """The simulator's `Dq_nextDq | Dq_nextDqa_cmd` (irs_lqr/quasistatic_dynamics.py:184-191,
+        `grad_from_active_constraints=True`): the derivative of the step QP's solution through its
+        ACTIVE constraints, contact geometry (J) held fixed.  With I the active rows, W_II = J_I D^-1 J_I',
+            S  = J_I' W_II^+ J_I       (b enters the QP linearly:   d dq / d b   = -D^-1 + D^-1 S D^-1)
+            Sn = J_I' W_II^+ Jn_I      (phi_i is a gap: d phi_i / d q = the NORMAL row Jn_i, the mean of the
+                                        contact's two generators;   d dq / d phi_I = -D^-1 J_I' W_II^+)
+        and b_a = K (q_a - u), D_aa = K on the actuated dofs, so in the internal order
+            B = E_a - D^-1 S[:, a],     A[:, l] = e_l - [l = a_j] B[:, j] - D^-1 Sn[:, l].
+        W_II is factorised by a masked LDL' in row order; a dependent active row (pivot below PIVOT_TOL W_ii)
+        is dropped -- the projector S does not depend on which one.  PINNED by the simulator's own Jacobians,
+        examples/box_pushing/analysis/dxdu_quasistatic.npy (tests/test_oracle_golden.py).  Returns (B, n, n+m)
+        in the reference's x order."""
+        x, u = np.atleast_2d(x), np.atleast_2d(u)
+        Dinv, b, J, W, lam = self._pgs(x, u)
+        Bn, nc, nq = J.shape
+        act_cols = np.asarray(self.ACT)
+        na = len(act_cols)
+        Jn = J.copy()
+        Jn[:, 0::2] = Jn[:, 1::2] = 0.5 * (J[:, 0::2] + J[:, 1::2])
+        Wd = np.einsum("bii->bi", W).copy()
+        active = lam * Wd > self.ACTIVE_TOL
+        Wm = W.copy()
+        Lm = np.zeros_like(W)
+        inv = np.zeros((Bn, nc))
+        for j in range(nc):
+            dj = Wm[:, j, j]
+            ok = active[:, j] & (dj > self.PIVOT_TOL * Wd[:, j])
+            inv[:, j] = np.where(ok, 1.0 / np.where(ok, dj, 1.0), 0.0)
+            for i in range(j + 1, nc):
+                Lm[:, i, j] = Wm[:, i, j] * inv[:, j]
+            for i in range(j + 1, nc):
+                for k in range(j + 1, i + 1):
+                    Wm[:, i, k] -= Lm[:, i, j] * Wm[:, k, j]
+        R = np.concatenate([J[:, :, act_cols], Jn], axis=2)          # (B, nc, na + nq) right-hand sides
+        Y = R.copy()
+        for j in range(nc):
+            for k in range(j):
+                Y[:, j] -= Lm[:, j, k, None] * Y[:, k]
+        Y *= inv[:, :, None]
+        for j in range(nc - 1, -1, -1):
+            for i in range(j + 1, nc):
+                Y[:, j] -= Lm[:, i, j, None] * Y[:, i]
+        SS = np.einsum("bik,bic->bkc", J, Y)                         # J' Y: (B, nq, na + nq)
+        B_int = -Dinv[None, :, None] * SS[:, :, :na]
+        B_int[:, act_cols, np.arange(na)] += 1.0
+        A_int = -Dinv[None, :, None] * SS[:, :, na:]
+        A_int[:, np.arange(nq), np.arange(nq)] += 1.0
+        for j, a in enumerate(act_cols):
+            A_int[:, :, a] -= B_int[:, :, j]
+        P = np.asarray(self.PERM)
+        n, m = nq, na
+        out = np.zeros((Bn, n, n + m))
+        out[:, P[:, None], P[None, :]] = A_int
+        out[:, P, n:] = B_int
+        return out
+
+    def jacobian_xu(self, x, u):
+        return self.jacobian_xu_batch(x[None], u[None])[0]
 
 
 class BoxOnBoxOracle(_ContactQPOracle):
@@ -337,6 +410,7 @@ class BoxOnBoxOracle(_ContactQPOracle):
     known answer (tests/test_oracle_golden.py)."""
 
     PERM = np.array([0, 1])
+    ACT = np.array([0])                          # internal indices of the actuated dofs
 
     def __init__(self, h=0.1, m=1.0, k=100.0, pgs_iters=50):
         self.h, self.m, self.k, self.pgs_iters = h, m, k, pgs_iters
@@ -390,6 +464,7 @@ class PlanarHandOracle(_ContactQPOracle):
         self.indices_u_into_x = self.PERM[3:].copy()
 
     PERM = np.array([0, 3, 6, 1, 4, 2, 5])       # internal q index -> index in the reference's x
+    ACT = np.array([3, 4, 5, 6])
 
     @classmethod
     def pack(cls, obj, left, right):
@@ -465,6 +540,7 @@ class BoxPivotOracle(_ContactQPOracle):
     (box mass and friction live in the absent box_1m_rotation.sdf / box_pivoting.yml)."""
 
     PERM = np.array([1, 3, 4, 0, 2])
+    ACT = np.array([3, 4])
 
     ground = True            # contacts with the ground y = 0 (and gravity) present
 
@@ -545,9 +621,13 @@ class BoxPushOracle(BoxPivotOracle):
     reference's own simulator data, examples/box_pushing/analysis/{xu,dxdu}_quasistatic.npy (committed
     as tests/golden/box_pushing_*.npy): an 80-step straight push recorded from the quasistatic
     simulator, row t+1 = (step(row t's state, row t+1's command), that command), plus the simulator's
-    Jacobians.  The data identify the parameters the absent SDF/YAML would hold: box mass 5
-    (= Kp h^2: hand and box share the first contact displacement equally), inertia 1/6 (the lateral
-    Jacobian entries), touching distance 0.5995 (half + r_hand; r_hand = 0.0995)."""
+    Jacobians [Dq_next/Dq | Dq_next/Dq_a_cmd] at every row.  The data identify the parameters the absent
+    SDF/YAML would hold: box mass 5 (= Kp h^2: hand and box share the first contact displacement
+    equally), touching distance 0.5995, and from the sticking-contact Jacobians (lateral entries
+    0.105430 / 0.894570, turning entry 1.579862 = 14.985 x the lateral one) the lever arm of the contact
+    point, 0.4995 = the box's half side, with inertia 1/6; so r_hand = 0.1.  With these the analytic
+    active-set derivative reproduces 79 of the simulator's 80 Jacobians to 5e-7 (the remaining one is
+    the contact-onset step, where the simulator's interior-point multiplier is 1e-5 instead of 0)."""
 
     ground = False
 
@@ -556,7 +636,8 @@ class BoxPushOracle(BoxPivotOracle):
         self.g = 0.0
         self.inertia = inertia
         self.kp = 500.0
-        self.r_hand = 0.0995
+        self.half = 0.4995
+        self.r_hand = 0.1
 
     def params(self):
         return [self.h, self.mass, self.inertia, self.half, self.mu, self.kp, self.r_hand, self.pgs_iters]
@@ -576,6 +657,47 @@ def zero_order_B_decoupled(system, x_trj, u_trj, du):
         Bt[t][idx, :] = np.eye(m)
         At[t] = np.eye(n)
         At[t][:, idx] = 0.0
+        ct[t] = ft - At[t].dot(x_trj[t]) - Bt[t].dot(u_trj[t])
+    return At, Bt, ct
+
+
+def _decouple(system, At, Bt):
+    """decouple_AB_matrices (irs_lqr/irs_lqr_quasistatic.py:275-284)."""
+    idx = system.indices_u_into_x
+    Bt[:, idx, :] = np.eye(system.dim_u)
+    At[:] = np.eye(system.dim_x)
+    At[:, :, idx] = 0.0
+    return At, Bt
+
+
+def first_order_B_decoupled(system, x_trj, u_trj, du):
+    """gradient_mode "first_order": calc_AB_first_order (irs_lqr/quasistatic_dynamics.py:193-208, u-only
+    noise, mean over the samples of the simulator's [Dq_nextDq | Dq_nextDqa_cmd]) followed by
+    decouple_AB_matrices, which keeps only the unactuated rows of the mean B; c = f - A x - B u
+    (irs_lqr_quasistatic.py:218-225)."""
+    T, n, m = u_trj.shape[0], system.dim_x, system.dim_u
+    At, Bt, ct = np.zeros((T, n, n)), np.zeros((T, n, m)), np.zeros((T, n))
+    for t in range(T):
+        AB = system.jacobian_xu_batch(np.tile(x_trj[t], (du.shape[1], 1)), u_trj[t] + du[t])
+        Bt[t] = AB[:, :, n:].mean(0)
+    At, Bt = _decouple(system, At, Bt)
+    for t in range(T):
+        ft = system.dynamics(x_trj[t], u_trj[t])
+        ct[t] = ft - At[t].dot(x_trj[t]) - Bt[t].dot(u_trj[t])
+    return At, Bt, ct
+
+
+def exact_contact_TV(system, x_trj, u_trj, decouple=True):
+    """gradient_mode "exact": calc_AB_exact (irs_lqr/quasistatic_dynamics.py:189-191) at every nominal
+    point, optional decouple_AB_matrices, c = f - A x - B u."""
+    T, n = u_trj.shape[0], system.dim_x
+    AB = system.jacobian_xu_batch(x_trj[:T], u_trj)
+    At, Bt = AB[:, :, :n].copy(), AB[:, :, n:].copy()
+    if decouple:
+        At, Bt = _decouple(system, At, Bt)
+    ct = np.zeros((T, n))
+    for t in range(T):
+        ft = system.dynamics(x_trj[t], u_trj[t])
         ct[t] = ft - At[t].dot(x_trj[t]) - Bt[t].dot(u_trj[t])
     return At, Bt, ct
 

@@ -731,8 +731,13 @@ def test_planar_hand_dynamics_vs_oracle(amd):
     got = sys_d.dynamics_batch(X, U)
     np.testing.assert_allclose(got, sys_o.dynamics_batch(X, U), rtol=0, atol=1e-10)
     np.testing.assert_allclose(sys_d.dynamics(X[0], U[0]), sys_o.dynamics(X[0], U[0]), rtol=0, atol=1e-10)
-    with pytest.raises(Exception):
-        sys_d.jacobian_xu(X[0], U[0])
+    # the step's active-set derivative (the simulator's Dq_nextDq | Dq_nextDqa_cmd), f64 on the device
+    U2 = x0[HAND_IDX] + 0.3 * rng.normal(size=(512, 4))
+    Jd, Jo = sys_d.jacobian_xu_batch(X, U2), sys_o.jacobian_xu_batch(X, U2)
+    np.testing.assert_allclose(Jd, Jo, rtol=0, atol=1e-8)
+    assert np.abs(Jo[:, HAND.PERM[:3], 7:]).max() > 0.1            # contacts are active in the batch
+    np.testing.assert_allclose(sys_d.jacobian_xu(X[0], U2[0]), Jo[0], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(sys_d.calc_AB_exact(X[1], U2[1]), Jo[1], rtol=0, atol=1e-8)
 
 
 def test_planar_hand_zero_order_B_decoupled_vs_oracle(amd):
@@ -757,9 +762,46 @@ def test_planar_hand_zero_order_B_decoupled_vs_oracle(amd):
     np.testing.assert_allclose(ct.cpu().numpy(), co, rtol=0, atol=2e-4)
     # the object rows of B see the contacts: pushing the fingers in moves the disc
     assert np.abs(Bo[:, HAND.PERM[:3], :]).max() > 0.05
-    # first-order smoothing is refused for a model without a Jacobian
-    with pytest.raises(Exception):
-        dm.smooth(1, xd, ud, dev.to_dev(np.zeros((T, N, 7), np.float32), dev.F32), dev.to_dev(du, dev.F32))
+
+
+def test_planar_hand_first_order_decoupled_vs_oracle(amd):
+    """gradient_mode "first_order" (calc_AB_first_order, quasistatic_dynamics.py:193-208, then
+    decouple_AB_matrices): every sample's contact step is differentiated through its active constraints
+    INSIDE the f32 sample pass and the n x m blocks are averaged.  Fused launch == accumulate over 3
+    shards + finalize == the f64 oracle on the same draws.  Tolerance: an f32 lane and the f64 oracle can
+    classify a borderline row (lam_i W_ii within rounding of the 1e-7 threshold, or a pivot at the drop
+    threshold) differently; one such sample moves the mean by O(1)/N."""
+    from irs_mpc_amd import device as dev
+    from irs_mpc_amd._lib import SMOOTH_FIRST_ORDER
+    T, N = 6, 3000
+    sys_d, sys_o, x0, u_trj = _hand_setup(amd, T)
+    x_trj = orc.rollout(sys_o, x0, u_trj)
+    rng = np.random.default_rng(13)
+    du = (rng.normal(size=(T, N, 4)) * 0.1).astype(np.float32)
+    dm = sys_d.dm()
+    xd, ud = dev.to_dev(x_trj), dev.to_dev(u_trj)
+    o = dm.smooth(SMOOTH_FIRST_ORDER, xd, ud, None, dev.to_dev(du, dev.F32))
+    assert int(o["info"].abs().sum().item()) == 0
+    Ao, Bo, co = orc.first_order_B_decoupled(sys_o, x_trj, u_trj, du.astype(np.float64))
+    At, Bt, ct = o["At"].cpu().numpy(), o["Bt"].cpu().numpy(), o["ct"].cpu().numpy()
+    np.testing.assert_allclose(At, Ao, rtol=0, atol=0)
+    np.testing.assert_allclose(Bt, Bo, rtol=0, atol=2e-3)
+    np.testing.assert_allclose(ct, co, rtol=0, atol=2e-3)
+    assert np.abs(Bo[:, HAND.PERM[:3], :]).max() > 0.05
+    # the estimator agrees with the zero-order one to Monte-Carlo accuracy (same smoothed dynamics)
+    Az, Bz, cz = orc.zero_order_B_decoupled(sys_o, x_trj, u_trj, du.astype(np.float64))
+    assert np.abs(Bz - Bo).max() < 0.15
+    # sharded: sums over 3 uneven shards, then the stand-alone solve
+    sums = None
+    for lo, hi in ((0, 1000), (1000, 1700), (1700, N)):
+        part = dm.smooth_accumulate(SMOOTH_FIRST_ORDER, xd, ud, None, dev.to_dev(np.ascontiguousarray(du[:, lo:hi]), dev.F32))
+        sums = part.clone() if sums is None else sums + part
+    A2, B2, c2, info = dm.smooth_finalize(SMOOTH_FIRST_ORDER, N, xd, ud, sums)
+    np.testing.assert_allclose(B2.cpu().numpy(), Bt, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(c2.cpu().numpy(), ct, rtol=0, atol=1e-6)
+    # device-drawn perturbations: same estimator, other draws
+    o2 = dm.smooth_rng(SMOOTH_FIRST_ORDER, xd, ud, N, None, np.full(4, 0.1), 7, 1)
+    assert np.abs(o2["Bt"].cpu().numpy() - Bt).max() < 0.1
 
 
 def test_planar_hand_descent_runs(amd):
@@ -1157,10 +1199,61 @@ def test_irs_lqr_quasistatic_zero_order_AB_mode(amd):
     c0 = sol.cost
     sol.iterate(2)
     assert sol.cost_best < c0
-    # the simulator-derivative modes stay refused
-    p.gradient_mode = "first_order"
+    # the sample-pass modes return the decoupled pair only
+    p.gradient_mode, p.decouple_AB = "first_order", False
     with pytest.raises(NotImplementedError):
         amd.IrsLqrQuasistatic(sys_d, p)
+    p.gradient_mode = "nope"
+    with pytest.raises(RuntimeError):
+        amd.IrsLqrQuasistatic(sys_d, p)
+
+
+@pytest.mark.parametrize("mode", ["first_order", "exact"])
+def test_quasistatic_simulator_gradient_modes(amd, mode):
+    """IrsLqrQuasistatic with the gradient modes that read the simulator's derivatives --
+    examples/planar_hand/planar_hand_setup.py:28 runs gradient_mode = "first_order" -- against the oracle:
+    get_TV_matrices on the reference's draws (np.random.seed), then descents that lower the cost."""
+    T, N = 10, 1500
+    sys_d, sys_o, x0, u_trj, _, _, _, (Q, Qd, R, xd) = _hand_problem(amd, T, 4, 0)
+    p = amd.IrsLqrQuasistaticParameters()
+    q_dict = {"sphere": np.array([1e-3, 1e-3, 10.0]), "arm_left": np.array([1e-3, 1e-3]),
+              "arm_right": np.array([1e-3, 1e-3])}
+    p.Q_dict, p.Qd_dict = q_dict, {k: 100 * v for k, v in q_dict.items()}
+    p.R_dict = {"arm_left": 5 * np.ones(2), "arm_right": 5 * np.ones(2)}
+    p.x0, p.x_trj_d, p.u_trj_0, p.T = x0, xd, u_trj, T
+    p.u_bounds_abs = np.array([-np.ones(4) * 0.05, np.ones(4) * 0.05])
+    p.sampling = lambda u_initial, it: u_initial / (it ** 0.8)
+    p.std_u_initial, p.num_samples = np.ones(4) * 0.1, N
+    p.publish_every_iteration = False
+    p.gradient_mode = mode
+    sol = amd.IrsLqrQuasistatic(sys_d, p)
+    sol.verbose = False
+    np.random.seed(5)
+    At, Bt, ct = sol.get_TV_matrices(sol.x_trj, sol.u_trj)
+    if mode == "first_order":
+        np.random.seed(5)
+        du = np.stack([np.random.normal(0, p.std_u_initial, size=[N, 4]) for _ in range(T)])
+        du = du.astype(np.float32).astype(np.float64)
+        Ao, Bo, co = orc.first_order_B_decoupled(sys_o, sol.x_trj, sol.u_trj, du)
+        tol = 3e-3
+    else:
+        Ao, Bo, co = orc.exact_contact_TV(sys_o, sol.x_trj, sol.u_trj, decouple=True)
+        tol = 1e-8
+    np.testing.assert_allclose(At, Ao, rtol=0, atol=0)
+    np.testing.assert_allclose(Bt, Bo, rtol=0, atol=tol)
+    np.testing.assert_allclose(ct, co, rtol=0, atol=tol)
+    c0 = sol.cost
+    sol.iterate(3)
+    assert sol.cost_best < c0
+    if mode == "exact":
+        p.decouple_AB = False
+        full = amd.IrsLqrQuasistatic(sys_d, p)
+        full.verbose = False
+        A2, B2, c2 = full.get_TV_matrices(full.x_trj, full.u_trj)
+        Af, Bf, cf = orc.exact_contact_TV(sys_o, full.x_trj, full.u_trj, decouple=False)
+        np.testing.assert_allclose(A2, Af, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(B2, Bf, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(c2, cf, rtol=0, atol=1e-8)
 
 
 def test_planar_hand_full_size_properties(amd):
@@ -1262,6 +1355,31 @@ def test_device_contact_step_reproduces_simulator_trajectory(amd, golden_dir):
     x_trj, _ = dm.rollout_cost(dev.to_dev(x[0]), dev.to_dev(u[1:]), dev.to_dev(np.eye(5)), dev.to_dev(np.eye(2)),
                                dev.to_dev(np.zeros((80, 5))))
     np.testing.assert_allclose(x_trj.cpu().numpy(), x, rtol=0, atol=2e-7)
+
+
+def test_device_active_set_jacobian_matches_simulator(amd, golden_dir):
+    """`jacobian_xu_batch` of the pinned functor (f64 lanes: contact step + masked LDL' of the active
+    rows) against all 80 of the simulator's [Dq_next/Dq | Dq_next/Dq_a_cmd] -- see
+    test_box_pushing_active_set_jacobian_matches_simulator for the one onset row -- and the f32 FIRST_ORDER
+    sample pass (N = 4096 u-perturbations of std 1e-4: the active set of every sample is the nominal one)
+    against the same data."""
+    from irs_mpc_amd import device as dev
+    from irs_mpc_amd._lib import SMOOTH_FIRST_ORDER
+    x, u, J = _box_pushing_data(golden_dir)
+    sys_d = amd.BoxPushingDynamics(0.1)
+    G = sys_d.jacobian_xu_batch(x, u)
+    err = np.abs(G - J).reshape(len(x), -1).max(1)
+    onset = int(np.argmax(err))
+    assert err[onset] < 2e-4 and np.delete(err, onset).max() < 5e-7
+    pts = [5, 12, 30, 40, 60, 78]
+    rng = np.random.default_rng(3)
+    du = (rng.normal(size=(len(pts), 4096, 2)) * 1e-4).astype(np.float32)
+    dm = sys_d.dm()
+    o = dm.smooth(SMOOTH_FIRST_ORDER, dev.to_dev(x[pts]), dev.to_dev(u[pts]), None, dev.to_dev(du, dev.F32))
+    Bt = o["Bt"].cpu().numpy()
+    for k, t in enumerate(pts):
+        np.testing.assert_allclose(Bt[k][[1, 3, 4]], J[t][[1, 3, 4], 5:], rtol=0, atol=2e-5)   # unactuated rows
+        np.testing.assert_allclose(Bt[k][[0, 2]], np.eye(2), rtol=0, atol=0)                  # decoupled
 
 
 def test_device_smoothing_matches_simulator_input_jacobian(amd, golden_dir):

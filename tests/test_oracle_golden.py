@@ -516,6 +516,69 @@ def test_box_pushing_step_reproduces_simulator_trajectory(golden_dir):
     np.testing.assert_allclose(xr, x, rtol=0, atol=2e-7)
 
 
+def test_box_pushing_active_set_jacobian_matches_simulator(golden_dir):
+    """PIN of the contact step's DERIVATIVE (gradient modes "exact" / "first_order"): the analytic
+    active-set Jacobian of the restated step against all 80 of the simulator's own
+    [Dq_next/Dq | Dq_next/Dq_a_cmd] (dxdu_quasistatic.npy), every row and column -- free flight,
+    contact onset, sticking contact with the friction-cone coupling that turns the box.  79 agree to
+    5e-7; the remaining one is the onset step (hand 0.5 mm from the box), where the simulator's
+    interior-point multiplier is 1e-5 rather than 0 and its Jacobian is that much off the active-set one."""
+    x, u, J = _box_pushing_data(golden_dir)
+    o = orc.BoxPushOracle(0.1)
+    G = o.jacobian_xu_batch(x, u)
+    err = np.abs(G - J).reshape(len(x), -1).max(1)
+    onset = int(np.argmax(err))
+    assert 0.0 < x[onset, 3] - x[onset, 2] - 0.5995 < 1e-3          # the one at the contact onset
+    assert err[onset] < 2e-4
+    assert np.delete(err, onset).max() < 5e-7
+    assert abs(G[40][4, 5] - 1.579862) < 1e-6 and abs(G[40][1, 5] - 0.1054295) < 1e-6   # sticking: drag + turn
+    np.testing.assert_allclose(o.jacobian_xu(x[40], u[40]), G[40], rtol=0, atol=0)
+
+
+def test_contact_jacobian_is_the_projector_formula():
+    """The masked-LDL' evaluation of the active-set derivative == its pseudo-inverse statement
+    B = E_a - D^-1 J_I' (J_I D^-1 J_I')^+ J_I[:, a] on planar-hand and box-pivoting samples with 1-6 active
+    rows, and == central differences of the exactly solved step with respect to u where the PGS active
+    set is the QP's (u enters the QP through b only, so that derivative has no geometry term)."""
+    hand = orc.PlanarHandOracle(0.1)
+    box = orc.BoxPivotOracle(0.1)
+    cases = [(hand, _hand_x0(), 0.1), (box, orc.BoxPivotOracle.pack([0.0, 0.5, 0.0], [-0.6, 0.3]), 0.05)]
+    rng = np.random.default_rng(5)
+    for o, x0, std in cases:
+        n, m = o.dim_x, o.dim_u
+        u0 = x0[o.indices_u_into_x]
+        N = 120
+        X, U = np.tile(x0, (N, 1)), u0 + rng.normal(0, std, (N, m))
+        G = o.jacobian_xu_batch(X, U)
+        counts = set()
+        n_fd = 0
+        for i in range(N):
+            Dinv, b, J, W, lam = o._pgs(X[i:i + 1], U[i:i + 1])
+            J, lam, W = J[0], lam[0], W[0]
+            act = lam * np.diag(W) > o.ACTIVE_TOL
+            counts.add(int(act.sum()))
+            JI = J[act]
+            S = JI.T.dot(np.linalg.pinv((JI * Dinv).dot(JI.T), rcond=1e-9)).dot(JI) if act.any() else np.zeros((n, n))
+            Bint = -(Dinv[:, None] * S)[:, o.ACT]
+            Bint[o.ACT, np.arange(m)] += 1.0
+            Bext = np.zeros((n, m))
+            Bext[o.PERM] = Bint
+            np.testing.assert_allclose(G[i][:, n:], Bext, rtol=0, atol=1e-10)
+            if i < 25:
+                xe = o.dynamics_exact(X[i], U[i])
+                if np.abs(xe - o.dynamics(X[i], U[i])).max() > 1e-7:
+                    continue                                  # PGS not converged here: another active set
+                fd = np.zeros((n, m))
+                for j in range(m):
+                    e = np.zeros(m)
+                    e[j] = 1e-6
+                    fd[:, j] = (o.dynamics_exact(X[i], U[i] + e) - o.dynamics_exact(X[i], U[i] - e)) / 2e-6
+                if np.abs(fd - G[i][:, n:]).max() < 2e-3:      # L-BFGS-B noise / step
+                    n_fd += 1
+        assert len(counts) >= 3 and max(counts) >= 4
+        assert n_fd >= 10
+
+
 def test_box_pushing_input_jacobian_matches_simulator(golden_dir):
     """The simulator's Dq_next/Dq_a_cmd (dxdu_quasistatic.npy[:, :, 5:]) against central differences of
     the restated step: free flight (identity rows), and sticking contact, where the hand drags and turns
