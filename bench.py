@@ -36,7 +36,7 @@ VALU_F32_PEAK_TFLOPS = 157.3  # peak FP32 (vector), same guide
 class Workload:
     """Everything that differs between the benchmarked configurations."""
 
-    def __init__(self, name, T=None):
+    def __init__(self, name, T=None, mode=None):
         from irs_mpc_amd import PendulumDynamics, PlanarHandDynamics
         from irs_mpc_amd import _lib
         self.name = name
@@ -71,6 +71,14 @@ class Workload:
             # per one-step evaluation of the contact QP (csrc/contact_models.hpp):
             # QP assembly ~1.5 kFLOP + 152 FLOP per PGS sweep + the Gram update
             self.flops_per_sample = 1500 + 152 * int(self.system.pgs_iters) + 76
+            if mode == "first_order":
+                # gradient_mode "first_order" (examples/planar_hand/planar_hand_setup.py:28): every sample's
+                # step is differentiated through its active constraints inside the sample pass -- masked
+                # LDL' of the 8x8 dual Hessian (196 FLOP), 4 right-hand sides (480), J'Y (448), B (56), sum (28)
+                self.mode, self.mode_name = _lib.SMOOTH_FIRST_ORDER, "FIRST_ORDER"
+                self.label = "planar_hand quasi-dynamic contact, first-order smoothing (per-sample active-set derivative)"
+                self.kernel = "smooth_kernel<PlanarHandModel, FIRST_ORDER>"
+                self.flops_per_sample = 1500 + 152 * int(self.system.pgs_iters) + 1208
         else:
             raise ValueError(name)
 
@@ -134,11 +142,23 @@ def main():
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="run all ranks on GPU 0 with gloo (exercises the N>1 code path on a 1-GPU box)")
     ap.add_argument("--sweep", action="store_true", help="also time N=1e3,1e5,1e6 (extra keys)")
+    ap.add_argument("--mode", default=None, choices=["first_order"],
+                    help="planar_hand: gradient_mode first_order instead of zero_order_B as the timed workload")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="several ranks: issue the step's launches one by one instead of replaying a HIP graph")
+    ap.add_argument("--force-unfused", action="store_true",
+                    help="one GPU: time the multi-GPU step (accumulate + all-reduce + solve) with a 1-rank RCCL group")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 20000 if args.workload == "pendulum" else 2000
     if args.warmup is None:
         args.warmup = max(1, args.steps // 10)
+
+    # stdout carries exactly ONE JSON line: native libraries print there too (RCCL's version banner at
+    # communicator creation), so file descriptor 1 is pointed at stderr and the line goes to a private copy
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,9 +173,14 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(args.backend)
+    elif args.force_unfused:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+    unfused = world > 1 or args.force_unfused
 
     from irs_mpc_amd import device as dev
-    from irs_mpc_amd.distributed import all_reduce_sums
+    from irs_mpc_amd.distributed import all_reduce_sums, capture_step
 
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -197,6 +222,8 @@ def main():
             el = float(t.item())
         return el, ev_ms
 
+    step_info = {}
+
     def run(w, N, steps, warmup):
         """Times the smoothing step and the full iLQR iteration of workload `w`."""
         dm = w.system.dm()
@@ -210,7 +237,7 @@ def main():
             dx = w.std_x * torch.randn((T, N, n), generator=g, device="cuda", dtype=torch.float32)
         du = w.std_u * torch.randn((T, N, m), generator=g, device="cuda", dtype=torch.float32)
         n_total = N * world
-        if world == 1:
+        if not unfused:
             plan = dev.SmoothPlan(dm, MODE, x_trj, u_trj, dx=dx, du=du, fuse=True)
             tv = plan.out
 
@@ -220,12 +247,26 @@ def main():
             plan = dev.SmoothPlan(dm, MODE, x_trj, u_trj, dx=dx, du=du, fuse=False, n_total=n_total)
             tv = {}
 
-            def smooth_step():
-                plan.run(stream)
-                all_reduce_sums(plan.sums)
+            def launches():
+                # sample pass -> (T,P) f64 statistics; ONE all-reduce; the solve (every rank, redundantly)
+                plan.run()
+                if args.force_unfused:
+                    dist.all_reduce(plan.sums)
+                else:
+                    all_reduce_sums(plan.sums)
                 tv["out"] = dm.smooth_finalize(MODE, n_total, x_trj, u_trj, plan.sums, out=tv.get("out"),
                                                workspace=plan.ws)
                 tv["At"], tv["Bt"], tv["ct"], tv["info"] = tv["out"]
+
+            launches()
+            smooth_step, step_info["graph"] = launches, False
+            if not args.no_graph and args.backend == "nccl":
+                # the three launches as one HIP graph: one host call per step
+                try:
+                    smooth_step, step_info["graph"] = capture_step(launches), True
+                except Exception as e:      # noqa: BLE001 -- an RCCL build that cannot be captured
+                    step_info["graph_error"] = repr(e)[:200]
+                    torch.cuda.synchronize()
 
         smooth_step()
         if w.name == "planar_hand":
@@ -262,7 +303,7 @@ def main():
         # `steps` launches of the timed region when the step is a single launch, otherwise
         # a dedicated loop of sample-pass launches.  Per-launch average = elapsed / launches
         # (back-to-back launches: includes the ~1 us dispatch gap, no per-event overhead).
-        if world == 1:
+        if not unfused:
             k_ms = ev_ms / steps
         else:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -285,7 +326,8 @@ def main():
         traffic, traffic_src = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_path):
-            key = "%s_%s_T%d_N%d" % (w.name, "zero" if w.name == "pendulum" else "zeroB", w.T, N)
+            tag = {"ZERO_ORDER_AB": "zero", "ZERO_ORDER_B": "zeroB", "FIRST_ORDER": "first"}[w.mode_name]
+            key = "%s_%s_T%d_N%d" % (w.name, tag, w.T, N)
             pmc = json.load(open(pmc_path)).get(key)
             if pmc and "FETCH_SIZE_raw_avg" in pmc:
                 traffic = (2.0 * pmc["FETCH_SIZE_raw_avg"] + pmc.get("WRITE_SIZE_raw_avg", 0.0)) * 1024.0
@@ -305,7 +347,7 @@ def main():
                               "vector rate, not HBM or MFMA; the HBM view of the same launch is under 'hbm'"})
         return r
 
-    w = Workload(args.workload, args.T)
+    w = Workload(args.workload, args.T, args.mode)
     N, T = args.N, w.T
     el, el_it, k_mean, nm = run(w, N, args.steps, args.warmup)
     out = {
@@ -327,6 +369,12 @@ def main():
                       "smoothing launch + Riccati + closed-loop rollout + cost (bounds inactive)"),
         "roofline": roofline(w, N, k_mean, nm),
     }
+    if unfused:
+        out["config"]["step"] = ("accumulate launch + all-reduce + solve launch, replayed as one HIP graph"
+                                 if step_info.get("graph") else
+                                 "accumulate launch + all-reduce + solve launch, issued one by one")
+        if "graph_error" in step_info:
+            out["config"]["graph_error"] = step_info["graph_error"]
     if args.sweep and world == 1:
         sweep = {}
         for Ns in (1000, 100000) + ((1000000,) if w.name == "pendulum" else ()):
@@ -335,7 +383,16 @@ def main():
             sweep[str(Ns)] = {"value": Ns * T * st / e, "ilqr_iters_per_s": st / ei,
                               "kernel_GBps": w.bytes_per_sample(*nm) * Ns * T / (km * 1e-3) / 1e9}
         out["sweep_N"] = sweep
-    if world == 1 and not args.no_secondary and w.name != "pendulum":
+    if world == 1 and not unfused and not args.no_secondary and w.name == "planar_hand" and args.mode is None:
+        # the reference's planar_hand set-up runs gradient_mode "first_order" (planar_hand_setup.py:28)
+        w1 = Workload("planar_hand", args.T, "first_order")
+        st1 = max(20, args.steps // 2)
+        e1, ei1, km1, nm1 = run(w1, N, st1, max(1, st1 // 10))
+        out["first_order"] = {"config": {"workload": w1.label, "T": w1.T, "N_per_gpu": N, "mode": w1.mode_name},
+                              "value": N * w1.T * st1 / e1, "unit": "rollouts*timesteps/s", "steps": st1,
+                              "ms_per_step": 1e3 * e1 / st1, "ilqr_iters_per_s": st1 / ei1,
+                              "roofline": roofline(w1, N, km1, nm1)}
+    if world == 1 and not unfused and not args.no_secondary and w.name != "pendulum":
         w2 = Workload("pendulum")
         st2 = 10000
         e2, ei2, km2, nm2 = run(w2, N, st2, 1000)
@@ -346,8 +403,9 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w, N)
-        print(json.dumps(out))
-    if world > 1:
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
+    if world > 1 or args.force_unfused:
         dist.destroy_process_group()
 
 

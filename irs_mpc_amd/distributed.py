@@ -39,3 +39,24 @@ def all_reduce_sums(sums, group=None):
         else:
             dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
     return sums
+
+
+def capture_step(fn, warmup=3):
+    """Captures `fn` -- a fixed sequence of launches on torch's current stream: C-ABI kernels, an RCCL
+    all-reduce, ... -- into a HIP graph and returns the replay callable: one host call per step instead
+    of one per launch (the multi-GPU smoothing step is three launches of ~70 us together, which a Python
+    host cannot issue fast enough one by one).  `fn` must read the stream from
+    torch.cuda.current_stream() at call time and must not allocate.  The capture runs on every rank at the
+    same point (the warm-up calls contain the collective)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warmup):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fn()
+    torch.cuda.synchronize()
+    return graph.replay
