@@ -36,10 +36,13 @@ VALU_F32_PEAK_TFLOPS = 157.3  # peak FP32 (vector), same guide
 class Workload:
     """Everything that differs between the benchmarked configurations."""
 
-    def __init__(self, name, T=None, mode=None):
+    def __init__(self, name, T=None, mode=None, host_only=False):
+        self.name = name
+        if host_only:           # a CPU-baseline worker process: only what the oracle needs, no GPU library
+            self._host_only(T, mode)
+            return
         from irs_mpc_amd import PendulumDynamics, PlanarHandDynamics
         from irs_mpc_amd import _lib
-        self.name = name
         if name == "pendulum":
             self.T = T or 30
             self.system = PendulumDynamics(0.05)
@@ -82,6 +85,18 @@ class Workload:
         else:
             raise ValueError(name)
 
+    def _host_only(self, T, mode):
+        from oracle import irs_oracle as orc
+        if self.name == "pendulum":
+            self.T = T or 30
+            self.x0, self.u_trj = np.zeros(2), np.tile(np.array([0.1]), (self.T, 1))
+            self.std_u, self.mode_name = 1.0, "ZERO_ORDER_AB"
+        else:
+            self.T = T or 50
+            self.x0 = orc.PlanarHandOracle.pack([0.0, 0.35, 0.0], [-np.pi / 4, -np.pi / 4], [np.pi / 4, np.pi / 4])
+            self.u_trj = np.tile(self.x0[orc.PlanarHandOracle.PERM[3:]], (self.T, 1))
+            self.std_u, self.mode_name = 0.3, "FIRST_ORDER" if mode == "first_order" else "ZERO_ORDER_B"
+
     def bytes_per_sample(self, n, m):
         """the f32 perturbations are read once."""
         return 4 * (m if self.name == "planar_hand" else n + m)
@@ -91,10 +106,9 @@ class Workload:
         return orc, (orc.PendulumOracle(0.05) if self.name == "pendulum" else orc.PlanarHandOracle(0.1))
 
 
-def cpu_baseline(w, N, seconds=12.0):
-    """The oracle (NumPy restatement with the reference's structure: Python loop over t,
-    vectorised dynamics_batch, SVD lstsq) timed on ONE host core on a bounded sample of the same
-    workload.  Reported, never the target."""
+def _cpu_problem(w, N):
+    """The bounded CPU sample of workload `w`: (one full pass as a callable over a range of timesteps,
+    samples per timestep, name of the oracle function)."""
     orc, s = w.oracle()
     T = w.T
     rng = np.random.default_rng(0)
@@ -104,16 +118,56 @@ def cpu_baseline(w, N, seconds=12.0):
         dx = rng.normal(size=(T, Ns, 2)).astype(np.float32).astype(np.float64)
         du = rng.normal(size=(T, Ns, 1)).astype(np.float32).astype(np.float64)
 
-        def once():
-            orc.zero_order_TV(s, x, w.u_trj, dx, du)
+        def part(t0, t1):
+            orc.zero_order_TV(s, x[t0:t1 + 1], w.u_trj[t0:t1], dx[t0:t1], du[t0:t1])
         what = "oracle.zero_order_TV"
     else:
         Ns = min(N, 2000)       # the vectorised PGS loop costs ~ms per 1000 samples per timestep
         du = (w.std_u * rng.normal(size=(T, Ns, 4))).astype(np.float32).astype(np.float64)
+        if w.mode_name == "FIRST_ORDER":
+            def part(t0, t1):
+                orc.first_order_B_decoupled(s, x[t0:t1 + 1], w.u_trj[t0:t1], du[t0:t1])
+            what = "oracle.first_order_B_decoupled"
+        else:
+            def part(t0, t1):
+                orc.zero_order_B_decoupled(s, x[t0:t1 + 1], w.u_trj[t0:t1], du[t0:t1])
+            what = "oracle.zero_order_B_decoupled"
+    return part, Ns, what
 
-        def once():
-            orc.zero_order_B_decoupled(s, x, w.u_trj, du)
-        what = "oracle.zero_order_B_decoupled"
+
+def _pool_worker(args):
+    """One worker of the pooled CPU baseline: its share of the timesteps, `reps` times, one thread."""
+    name, T, mode, N, t0, t1, reps = args
+    os.environ["OMP_NUM_THREADS"] = "1"
+    try:
+        import threadpoolctl
+        threadpoolctl.threadpool_limits(1)
+    except Exception:       # noqa: BLE001
+        pass
+    part, _, _ = _cpu_problem(Workload(name, T, mode, host_only=True), N)
+    t_start = time.perf_counter()
+    for _ in range(reps):
+        part(t0, t1)
+    return time.perf_counter() - t_start
+
+
+def cpu_baseline(w, N, seconds=12.0, pool_cores=16):
+    """The oracle (NumPy restatement with the reference's structure: Python loop over t, vectorised
+    dynamics_batch, SVD lstsq) timed on the GPU box's host on a bounded sample of the same workload:
+    on ONE core, and -- the honest analogue of the reference's 18-30 ZMQ worker processes, which split
+    the timesteps among themselves (irs_lqr_quasistatic.py:245-263) -- on a pool of `pool_cores`
+    single-threaded processes (the one-GPU box's CPU share).  Reported, never the target."""
+    import multiprocessing as mp
+    part, Ns, what = _cpu_problem(w, N)
+    T = w.T
+
+    def once():
+        part(0, T)
+    try:
+        import threadpoolctl
+        limit = threadpoolctl.threadpool_limits(1)      # "cores": 1 means one BLAS thread too
+    except Exception:       # noqa: BLE001
+        limit = None
     once()
     reps, t0 = 0, time.perf_counter()
     while True:
@@ -122,10 +176,31 @@ def cpu_baseline(w, N, seconds=12.0):
         el = time.perf_counter() - t0
         if el > seconds or reps >= 2000:
             break
-    return {"value": T * Ns * reps / el, "unit": "rollouts*timesteps/s", "cores": 1, "kind": "port",
-            "sample": "%d passes of T=%d N=%d of the same workload (%s, supplied samples, 1 thread, %.1f s)"
-                      % (reps, T, Ns, what, el),
-            "host_cpus": os.cpu_count()}
+    if limit is not None:
+        limit.restore_original_limits()
+    out = {"value": T * Ns * reps / el, "unit": "rollouts*timesteps/s", "cores": 1, "kind": "port",
+           "sample": "%d passes of T=%d N=%d of the same workload (%s, supplied samples, 1 thread, %.1f s)"
+                     % (reps, T, Ns, what, el),
+           "host_cpus": os.cpu_count()}
+    # pooled: the timesteps dealt out to `cores` processes, each repeating its share `reps_p` times
+    cores = max(1, min(pool_cores, os.cpu_count() or 1, T))
+    try:
+        reps_p = max(1, int(reps * min(1.0, 8.0 / max(el, 1e-9))))        # ~8 s of work per worker
+        bounds = [round(i * T / cores) for i in range(cores + 1)]
+        jobs = [(w.name, w.T, "first_order" if w.mode_name == "FIRST_ORDER" else None, N, bounds[i], bounds[i + 1], reps_p)
+                for i in range(cores) if bounds[i + 1] > bounds[i]]
+        ctx = mp.get_context("spawn")
+        t0 = time.perf_counter()
+        with ctx.Pool(len(jobs)) as pool:
+            busy = pool.map_async(_pool_worker, jobs).get(timeout=180)
+        wall = time.perf_counter() - t0
+        out["pool"] = {"value": T * Ns * reps_p / max(busy), "unit": "rollouts*timesteps/s", "cores": len(jobs),
+                       "sample": "%d passes of T=%d N=%d, timesteps dealt out to %d single-threaded processes; "
+                                 "slowest worker %.1f s (%.1f s with process start-up)"
+                                 % (reps_p, T, Ns, len(jobs), max(busy), wall)}
+    except Exception as e:      # noqa: BLE001 -- the pooled figure is an extra; never fail the bench on it
+        out["pool"] = {"error": repr(e)[:200]}
+    return out
 
 
 def main():
@@ -164,6 +239,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    # the CPU baseline runs FIRST, before this process initialises the GPU: its pooled leg starts worker
+    # processes (fresh interpreters), which a process that already holds the GPU must not do on this pool
+    cpu_base = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.force_unfused:
+        cpu_base = cpu_baseline(Workload(args.workload, args.T, args.mode, host_only=True), args.N)
     if args.rehearse_one_gpu:       # testing aid: every rank on GPU 0, gloo collectives
         local, args.backend = 0, "gloo"
     torch.cuda.set_device(local)
@@ -401,8 +481,8 @@ def main():
                            "ms_per_step": 1e3 * e2 / st2, "ilqr_iters_per_s": st2 / ei2,
                            "roofline": roofline(w2, N, km2, nm2)}
     if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(w, N)
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
     if world > 1 or args.force_unfused:
