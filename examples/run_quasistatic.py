@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--N", type=int, default=1000, help="samples per timestep / CEM batch size")
     ap.add_argument("--bounds", choices=["abs", "rel", "none"], default=None,
                     help="default: the script's own (planar_hand: abs, box_pivoting: rel)")
+    ap.add_argument("--gradient-mode", default=None, choices=["zero_order_B", "zero_order_AB", "first_order", "exact"],
+                    help="default: the reference's set-up files (planar_hand_setup.py:28 first_order; "
+                         "box_pivoting_setup.py / box_pushing_setup.py:25 zero_order_B)")
     ap.add_argument("--device-rng", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--csv", default=None)
@@ -112,6 +115,7 @@ def main():
             params.sampling = lambda u_initial, it: u_initial ** (0.5 * it)     # run_box_pivoting.py:122-126
             params.std_u_initial = np.ones(dim_u) * 0.1
         params.num_samples = a.N
+        params.gradient_mode = a.gradient_mode or ("first_order" if hand else "zero_order_B")
         params.publish_every_iteration = False
         if a.device_rng:
             params.device_rng_seed = a.seed

@@ -687,6 +687,29 @@ def first_order_B_decoupled(system, x_trj, u_trj, du):
     return At, Bt, ct
 
 
+def first_order_sums(system, x_trj, u_trj, du):
+    """The (T, n*m) statistics of the contact first-order sample pass (include/irs_hip.h,
+    IRS_SMOOTH_FIRST_ORDER on a contact model): per time step the SUM over this shard's samples of the
+    n x m block B of the step's active-set derivative, row-major in the reference's x order."""
+    T, n = u_trj.shape[0], system.dim_x
+    out = np.zeros((T, n * system.dim_u))
+    for t in range(T):
+        AB = system.jacobian_xu_batch(np.tile(x_trj[t], (du.shape[1], 1)), u_trj[t] + du[t])
+        out[t] = AB[:, :, n:].sum(0).reshape(-1)
+    return out
+
+
+def first_order_from_sums(system, x_trj, u_trj, sums, n_total):
+    """The solve launch of that mode: mean B inside the decoupled structure, c = f - A x - B u."""
+    T, n, m = u_trj.shape[0], system.dim_x, system.dim_u
+    At, Bt, ct = np.zeros((T, n, n)), (np.asarray(sums) / float(n_total)).reshape(T, n, m), np.zeros((T, n))
+    At, Bt = _decouple(system, At, Bt)
+    for t in range(T):
+        ft = system.dynamics(x_trj[t], u_trj[t])
+        ct[t] = ft - At[t].dot(x_trj[t]) - Bt[t].dot(u_trj[t])
+    return At, Bt, ct
+
+
 def exact_contact_TV(system, x_trj, u_trj, decouple=True):
     """gradient_mode "exact": calc_AB_exact (irs_lqr/quasistatic_dynamics.py:189-191) at every nominal
     point, optional decouple_AB_matrices, c = f - A x - B u."""

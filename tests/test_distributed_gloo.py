@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _problem(name, T):
     """(oracle system, nominal x, u, perturbation scales, contact-model sums layout?)"""
     from oracle import irs_oracle as orc
+    name = name.replace("_first_order", "")
     if name == "pendulum":
         s = orc.PendulumOracle(0.05)
         u = np.tile(np.array([0.1]), (T, 1))
@@ -38,9 +39,14 @@ def _worker(rank, world, port, T, N, out_dir, name="pendulum"):
     rng = np.random.default_rng(0)              # every rank draws the same full set
     dx, du = sx * rng.normal(size=(T, N, s.dim_x)), su * rng.normal(size=(T, N, s.dim_u))
     lo, hi = shard_range(N, rank, world)
-    sums = torch.from_numpy(orc.zero_order_sums(s, x, u, dx[:, lo:hi], du[:, lo:hi], sum_z=sum_z))
-    all_reduce_sums(sums)
-    At, Bt, ct = orc.zero_order_from_sums(s, x, u, sums.numpy())
+    if name == "planar_hand_first_order":
+        sums = torch.from_numpy(orc.first_order_sums(s, x, u, du[:, lo:hi]))
+        all_reduce_sums(sums)
+        At, Bt, ct = orc.first_order_from_sums(s, x, u, sums.numpy(), N)
+    else:
+        sums = torch.from_numpy(orc.zero_order_sums(s, x, u, dx[:, lo:hi], du[:, lo:hi], sum_z=sum_z))
+        all_reduce_sums(sums)
+        At, Bt, ct = orc.zero_order_from_sums(s, x, u, sums.numpy())
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), At=At, Bt=Bt, ct=ct, lo=lo, hi=hi)
     dist.destroy_process_group()
 
@@ -84,6 +90,27 @@ def test_two_rank_sharded_smoothing_contact_model_layout(tmp_path):
     np.testing.assert_allclose(r0["At"], At, rtol=1e-7, atol=1e-8)
     np.testing.assert_allclose(r0["Bt"], Bt, rtol=1e-7, atol=1e-8)
     np.testing.assert_allclose(r0["ct"], ct, rtol=1e-7, atol=1e-8)
+
+
+def test_two_rank_sharded_first_order_contact_model(tmp_path):
+    """gradient_mode "first_order" on a contact model: each rank sums the per-sample active-set
+    derivative blocks of its shard, ONE all-reduce of the (T, n m) f64 sums, the same solve everywhere ==
+    the unsharded mean (oracle.first_order_B_decoupled)."""
+    from oracle import irs_oracle as orc
+    T, N, world = 3, 201, 2
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(world, port, T, N, str(tmp_path), "planar_hand_first_order"), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    for k in ("At", "Bt", "ct"):
+        assert np.array_equal(r0[k], r1[k])
+    s, x, u, sx, su, _ = _problem("planar_hand", T)
+    rng = np.random.default_rng(0)
+    _, du = sx * rng.normal(size=(T, N, 7)), su * rng.normal(size=(T, N, 4))
+    At, Bt, ct = orc.first_order_B_decoupled(s, x, u, du)
+    np.testing.assert_allclose(r0["At"], At, rtol=0, atol=0)
+    np.testing.assert_allclose(r0["Bt"], Bt, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(r0["ct"], ct, rtol=0, atol=1e-12)
+    assert np.abs(Bt[:, orc.PlanarHandOracle.PERM[:3], :]).max() > 0.05
 
 
 def test_shard_range_partitions():
