@@ -343,7 +343,18 @@ def main():
             if not args.no_graph and args.backend == "nccl":
                 # the three launches as one HIP graph: one host call per step
                 try:
-                    smooth_step, step_info["graph"] = capture_step(launches), True
+                    torch.cuda.synchronize()
+                    ref = [tv[k].clone() for k in ("At", "Bt", "ct")]
+                    replay = capture_step(launches)
+                    for k in ("At", "Bt", "ct"):
+                        tv[k].zero_()
+                    replay()
+                    torch.cuda.synchronize()
+                    # the replayed step must reproduce the eagerly issued one bit for bit (fixed-order sums)
+                    if all(torch.equal(a, tv[k]) for a, k in zip(ref, ("At", "Bt", "ct"))):
+                        smooth_step, step_info["graph"] = replay, True
+                    else:
+                        step_info["graph_error"] = "replayed step differs from the eager one; eager step timed"
                 except Exception as e:      # noqa: BLE001 -- an RCCL build that cannot be captured
                     step_info["graph_error"] = repr(e)[:200]
                     torch.cuda.synchronize()
