@@ -185,7 +185,7 @@ def cpu_baseline(w, N, seconds=12.0, pool_cores=16):
     # pooled: the timesteps dealt out to `cores` processes, each repeating its share `reps_p` times
     cores = max(1, min(pool_cores, os.cpu_count() or 1, T))
     try:
-        reps_p = max(1, int(reps * min(1.0, 8.0 / max(el, 1e-9))))        # ~8 s of work per worker
+        reps_p = max(1, int(reps * 6.0 / max(el, 1e-9) * cores))          # ~6-8 s of work per worker
         bounds = [round(i * T / cores) for i in range(cores + 1)]
         jobs = [(w.name, w.T, "first_order" if w.mode_name == "FIRST_ORDER" else None, N, bounds[i], bounds[i + 1], reps_p)
                 for i in range(cores) if bounds[i + 1] > bounds[i]]
