@@ -57,8 +57,10 @@ typedef enum irs_model_id {
                                  Anitescu convex step; x = [xo, ql1, qr1, yo, ql2, qr2, th] (the reference's order,
                                  planar_hand_analysis.py:61-67), u = [ql1, ql2, qr1, qr2] joint commands;
                                  params = {h, g, mass, R, mu, kp1, kp2, l1, l2, r_link, base_x, pgs_iters};
-                                 no Jacobian: FIRST_ORDER / exact are unsupported, ZERO_ORDER_B returns the
-                                 decoupled (A,B) of irs_lqr_quasistatic.py:275-284.  PARITY UNPINNED.    */
+                                 Jacobian = the step QP's active-set derivative (the simulator's Dq_nextDq |
+                                 Dq_nextDqa_cmd, quasistatic_dynamics.py:184-191); the sample-pass modes
+                                 ZERO_ORDER_B / FIRST_ORDER perturb u only and return the decoupled (A,B) of
+                                 irs_lqr_quasistatic.py:275-284.  PARITY UNPINNED.                       */
     IRS_MODEL_BOX_PIVOT = 5   /* examples/box_pivoting: a 1 m square box on the ground pivoted by a position-
                                  controlled disc; x = [x_h, x_b, y_h, y_b, th_b] (box_pivoting_analysis.py:53-64),
                                  u = commanded hand position; params = {h, g, mass, half, mu, kp, r_hand,
@@ -75,7 +77,9 @@ typedef enum irs_model_id {
 /* Smoothing estimators.                                                         */
 typedef enum irs_smooth_mode {
     IRS_SMOOTH_ZERO_ORDER_AB = 0, /* irs_lqr/irs_lqr_zero_order.py:38-63 (LSQ fit through N one-step evals) */
-    IRS_SMOOTH_FIRST_ORDER = 1,   /* irs_lqr/irs_lqr_first_order.py:28-54 (mean of N sampled Jacobians)     */
+    IRS_SMOOTH_FIRST_ORDER = 1,   /* irs_lqr/irs_lqr_first_order.py:28-54 (mean of N sampled Jacobians); on a
+                                     contact model: calc_AB_first_order, irs_lqr/quasistatic_dynamics.py:193-208
+                                     (u-only noise, dx may be NULL; sums = (T, n*m): the B blocks; decoupled)  */
     IRS_SMOOTH_ZERO_ORDER_B = 2   /* irs_lqr/quasistatic_dynamics.py:242-266 (u-only noise: B by LSQ,
                                      A = exact Jacobian at the nominal point)                               */
 } irs_smooth_mode;
@@ -95,7 +99,9 @@ int irs_dynamics_batch(int model, const double *params, int n_params,
 
 /* jacobian_xu_batch (:53-66): J[b] = df/d[x,u] at (X[b],U[b]); J (B,n,n+m) DEV f64.
  * Forward-mode AD of the device functor, like the reference's forwarddiff/symbolic
- * Jacobians (quadrotor_dynamics.py:136-148, pendulum_dynamics.py:110-127).        */
+ * Jacobians (quadrotor_dynamics.py:136-148, pendulum_dynamics.py:110-127); contact models:
+ * the derivative of the step QP through its active constraints, contact geometry fixed =
+ * QuasistaticDynamics.jacobian_xu (irs_lqr/quasistatic_dynamics.py:184-191).           */
 int irs_jacobian_xu_batch(int model, const double *params, int n_params,
                           const double *X, const double *U, int B, double *J, void *stream);
 
