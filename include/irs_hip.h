@@ -296,6 +296,23 @@ int irs_quasistatic_box_descent(int model, const double *params, int n_params, i
                                 const double *du_lo, const double *du_hi,
                                 int solver, double rho, double relax, int max_iter, double eps,
                                 double *x_new, double *u_new, double *cost, int *info, void *stream);
+/* The same with the active set of the FIRST tail handed from one iLQR iteration to the next.
+ * act_io (T,m) DEV f64 in {-1: at the lower bound, 0: free, +1: at the upper bound}, may be NULL
+ * (= irs_quasistatic_box_descent).  In: the set the first tail's solve starts from (all zeros = cold
+ * start; any content is valid, the QP's solution does not depend on it); out: the set that tail
+ * converged to.  Consecutive iterations of IrsLqrQuasistatic.iterate (irs_lqr_quasistatic.py:349-385)
+ * bind nearly the same bounds, so the cold start of tail 0 -- up to 40 % of a descent -- shrinks to a
+ * few sweeps.  Used by the active-set solver only (ADMM ignores it).                                  */
+int irs_quasistatic_box_descent_ws(int model, const double *params, int n_params, int T,
+                                   const double *At, const double *Bt, const double *ct,
+                                   const double *Q, const double *Qd, const double *R,
+                                   const double *xd_trj, const double *x0,
+                                   const double *x_lo, const double *x_hi,
+                                   const double *u_lo, const double *u_hi,
+                                   const double *du_lo, const double *du_hi,
+                                   int solver, double rho, double relax, int max_iter, double eps,
+                                   double *x_new, double *u_new, double *cost, int *info,
+                                   double *act_io, void *stream);
 size_t irs_quasistatic_box_lds_bytes(int model, int T, int solver);
 
 /* ---- Cross-entropy-method baseline (irs_lqr/cem.py:151-184) -------------------- */

@@ -479,6 +479,7 @@ int irs_tvlqr_box_descent(int model, const double* params, int n_params, int T, 
                   x_new && u_new && info, "bad argument");
     IRS_CHECK_ARG(rho > 0.0 && relax > 0.0 && relax < 2.0 && max_iter > 0 && eps > 0.0, "bad ADMM parameter");
     BoxArgs a;
+    a.act_io = nullptr;
     int rc = irs_load_params(model, params, n_params, &a.p);
     if (rc != IRS_OK) return rc;
     a.At = At; a.Bt = Bt; a.ct = ct; a.Q = Q; a.Qd = Qd; a.R = R; a.xd = xd_trj; a.x0 = x0;
@@ -500,12 +501,26 @@ int irs_quasistatic_box_descent(int model, const double* params, int n_params, i
                                 const double* u_hi, const double* du_lo, const double* du_hi,
                                 int solver, double rho, double relax, int max_iter, double eps,
                                 double* x_new, double* u_new, double* cost, int* info, void* stream) {
+    return irs_quasistatic_box_descent_ws(model, params, n_params, T, At, Bt, ct, Q, Qd, R, xd_trj, x0, x_lo, x_hi,
+                                          u_lo, u_hi, du_lo, du_hi, solver, rho, relax, max_iter, eps, x_new,
+                                          u_new, cost, info, nullptr, stream);
+}
+
+int irs_quasistatic_box_descent_ws(int model, const double* params, int n_params, int T, const double* At,
+                                   const double* Bt, const double* ct, const double* Q, const double* Qd,
+                                   const double* R, const double* xd_trj, const double* x0,
+                                   const double* x_lo, const double* x_hi, const double* u_lo,
+                                   const double* u_hi, const double* du_lo, const double* du_hi,
+                                   int solver, double rho, double relax, int max_iter, double eps,
+                                   double* x_new, double* u_new, double* cost, int* info, double* act_io,
+                                   void* stream) {
     IRS_CHECK_ARG(T > 0 && At && Bt && ct && Q && Qd && R && xd_trj && x0 && x_new && u_new && info, "bad argument");
     IRS_CHECK_ARG(solver >= 0 && solver <= 2, "solver must be 0 (auto), 1 (ADMM) or 2 (active set)");
     IRS_CHECK_ARG((x_lo == nullptr) == (x_hi == nullptr) && (u_lo == nullptr) == (u_hi == nullptr) &&
                   (du_lo == nullptr) == (du_hi == nullptr), "give both sides of a bound or neither");
     IRS_CHECK_ARG(rho > 0.0 && relax > 0.0 && relax < 2.0 && max_iter > 0 && eps > 0.0, "bad ADMM parameter");
     BoxArgs a;
+    a.act_io = act_io;
     int rc = irs_load_params(model, params, n_params, &a.p);
     if (rc != IRS_OK) return rc;
     int n, m, np;

@@ -17,6 +17,10 @@ struct BoxArgs {
                                              // [2] number of tail problems that hit max_iter
     double alpha, rho, relax, eps;
     int T, max_iter;
+    // active-set solver only (may be null): (T,m) in {-1 at lo, 0 free, +1 at hi}.  In: the active set
+    // the FIRST tail starts from (zeros = cold start); out: the set that tail converged to -- what the
+    // next iLQR iteration's descent should start from
+    double* act_io;
 };
 
 // position-controlled models expose indices_u_into_x (quasistatic_dynamics.py:57-65)

@@ -146,9 +146,15 @@ __global__ __launch_bounds__(64) void ctrlbox_descent_kernel(BoxArgs a) {
             rec[L::oqsd + lane] = sq;                  // (Qs sd_t)[:NR]; the w block of sd is zero
         }
         if (lane < M) {
-            rec[L::olo + lane] = blo ? blo[(size_t)t * bs + lane] : -INF;
-            rec[L::ohi + lane] = bhi ? bhi[(size_t)t * bs + lane] : INF;
-            rec[L::oact + lane] = 0.0;
+            const double lo_ = blo ? blo[(size_t)t * bs + lane] : -INF;
+            const double hi_ = bhi ? bhi[(size_t)t * bs + lane] : INF;
+            rec[L::olo + lane] = lo_;
+            rec[L::ohi + lane] = hi_;
+            // warm start of the first tail (the previous iLQR iteration's converged set), cleaned:
+            // {-1, 0, +1}, and nothing pinned at an infinite bound
+            double a0 = a.act_io ? a.act_io[(size_t)t * M + lane] : 0.0;
+            a0 = a0 < 0.0 ? (lo_ > -INF ? -1.0 : 0.0) : (a0 > 0.0 ? (hi_ < INF ? 1.0 : 0.0) : 0.0);
+            rec[L::oact + lane] = a0;
             rec[L::ou + lane] = 0.0;
             rec[L::ous + lane] = 0.0;
             rec[L::omu + lane] = 0.0;
@@ -577,6 +583,9 @@ __global__ __launch_bounds__(64) void ctrlbox_descent_kernel(BoxArgs a) {
         it_max = max(it_max, iters);
         n_fail += conv ? 0 : 1;
         full = !conv;
+        if (tau == 0 && a.act_io != nullptr) {
+            for (int q = lane; q < T * M; q += 64) a.act_io[q] = rec_(q / M)[L::oact + q % M];
+        }
         // first control of the tail solution (clipped), true dynamics step
         {
             const double* rec = rec_(tau);

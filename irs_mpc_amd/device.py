@@ -183,10 +183,12 @@ class DeviceModel:
 
     def quasistatic_box_descent(self, At, Bt, ct, Q, Qd, R, xd_trj, x0, x_lo=None, x_hi=None, u_lo=None,
                                 u_hi=None, du_lo=None, du_hi=None, solver=0, rho=10.0, relax=1.6,
-                                max_iter=5000, eps=1e-8, out=None):
+                                max_iter=5000, eps=1e-8, out=None, act=None):
         """IrsLqrQuasistatic.local_descent after get_TV_matrices (irs_lqr_quasistatic.py:286-345) +
         eval_cost.  Bounds are absolute per-time rows ((T+1,n) / (T,m)) or None.  solver: 0 auto,
-        1 ADMM, 2 active set (one control box, no x bounds).  Returns dict(x_new, u_new, cost, info[3])."""
+        1 ADMM, 2 active set (one control box, no x bounds).  `act` (T,m) f64 in {-1,0,+1}, in/out: the
+        active set the first tail starts from / converged to (hand it from one iteration's descent to the
+        next; zeros = cold start).  Returns dict(x_new, u_new, cost, info[3])."""
         T = At.shape[0]
         dev = At.device
         o = out
@@ -198,12 +200,13 @@ class DeviceModel:
         for b, shape in ((x_lo, (T + 1, self.n)), (x_hi, (T + 1, self.n)), (u_lo, (T, self.m)),
                          (u_hi, (T, self.m)), (du_lo, (T, self.m)), (du_hi, (T, self.m))):
             assert b is None or tuple(b.shape) == shape, (tuple(b.shape), shape)
-        check(self.lib.irs_quasistatic_box_descent(
+        assert act is None or tuple(act.shape) == (T, self.m)
+        check(self.lib.irs_quasistatic_box_descent_ws(
             self.model_id, self._p, self._np, T, _ptr(At, F64), _ptr(Bt, F64), _ptr(ct, F64), _ptr(Q, F64),
             _ptr(Qd, F64), _ptr(R, F64), _ptr(xd_trj, F64), _ptr(x0, F64), _ptr(x_lo, F64), _ptr(x_hi, F64),
             _ptr(u_lo, F64), _ptr(u_hi, F64), _ptr(du_lo, F64), _ptr(du_hi, F64), int(solver), float(rho),
             float(relax), int(max_iter), float(eps), _ptr(o["x_new"], F64), _ptr(o["u_new"], F64), _ptr(o["cost"], F64),
-            o["info"].data_ptr(), _stream()), "irs_quasistatic_box_descent")
+            o["info"].data_ptr(), _ptr(act, F64), _stream()), "irs_quasistatic_box_descent_ws")
         return o
 
     # ---- CEM baseline -------------------------------------------------------

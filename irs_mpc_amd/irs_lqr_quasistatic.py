@@ -102,6 +102,7 @@ class IrsLqrQuasistatic(QuasistaticOptimizerBase):
         if not dm.quasistatic_descent_supported(params.T, self._solver):
             raise NotImplementedError("horizon T=%d does not fit the LDS-resident QP factorisation" % params.T)
         self._setup(q_dynamics, params, params.x_trj_d)
+        self._act = None
         self._idx = torch.as_tensor(np.asarray(self.indices_u_into_x), device=self._x0.device)
         # kept for interface parity; the bounded QPs are solved on the device
         self.solver = get_solver(params.solver_name)
@@ -239,11 +240,16 @@ class IrsLqrQuasistatic(QuasistaticOptimizerBase):
     def _local_descent_dev(self, x_trj, u_trj):
         At, Bt, ct = self._get_TV_matrices_dev(x_trj, u_trj)
         p = self.params
+        if self._solver == 2 and getattr(self, "_act", None) is None:
+            # the active set of the first tail, handed from one iteration's descent to the next: consecutive
+            # iterations bind nearly the same bounds (the QP's solution does not depend on the start)
+            self._act = torch.zeros((self.T, self.dim_u), dtype=dev.F64, device=x_trj.device)
         o = self._dm.quasistatic_box_descent(At, Bt, ct, self._Q, self._Qd, self._R, self._xd,
                                              x_trj[0].contiguous(), *self._bounds_dev(x_trj),
                                              solver=self._solver, rho=getattr(p, "qp_rho", 100.0),
                                              max_iter=getattr(p, "qp_max_iter", 20000),
-                                             eps=getattr(p, "qp_eps", 1e-9))
+                                             eps=getattr(p, "qp_eps", 1e-9),
+                                             act=self._act if self._solver == 2 else None)
         self._last = dict(At=At, Bt=Bt, ct=ct, info=o["info"])
         return o["x_new"], o["u_new"], o["cost"]
 

@@ -1498,15 +1498,20 @@ def ctrlbox_workspace(prob):
 
 
 def local_descent_quasistatic_as(system, At, Bt, ct, Q, Qd, R, x0, xd_trj, lo, hi, kind, pdas_iter=10,
-                                 max_iter=2000, tol=1e-10):
+                                 max_iter=2000, tol=1e-10, act_io=None):
     """irs_lqr_quasistatic.py:326-345 with ONE control box (kind "abs": lo,hi (T,m) absolute rows
     on u_t; kind "rel": rows on u_t - u_{t-1}): T tail QPs solved EXACTLY by the active-set method,
-    the active set and the backward pass carried from tail to tail."""
+    the active set and the backward pass carried from tail to tail.  `act_io` (T,m) in {-1,0,+1}, in/out
+    (include/irs_hip.h, irs_quasistatic_box_descent_ws): the set the first tail starts from (a previous
+    iteration's) and, on return, the set it converged to."""
     T, n, m = Bt.shape
     idx = system.indices_u_into_x
     prob = quasistatic_ctrl_problem(At, Bt, ct, Q, Qd, R, xd_trj, kind)
     W = ctrlbox_workspace(prob)
     act = np.zeros((T, m), dtype=int)
+    if act_io is not None:
+        a0 = np.sign(np.asarray(act_io)).astype(int)
+        act[:] = np.where((a0 < 0) & np.isfinite(lo), -1, np.where((a0 > 0) & np.isfinite(hi), 1, 0))
     x_new, u_new = np.zeros((T + 1, n)), np.zeros((T, m))
     x_new[0] = x0
     stats, valid_from = [], T
@@ -1516,6 +1521,8 @@ def local_descent_quasistatic_as(system, At, Bt, ct, Q, Qd, R, x0, xd_trj, lo, h
         s, u, mu, st, valid_from = ctrlbox_solve(prob, s_t, t, lo, hi, u, act, W, valid_from, pdas_iter,
                                                  max_iter, tol)
         stats.append(st)
+        if t == 0 and act_io is not None:
+            act_io[:] = act
         ctl = np.clip(u[t], lo[t], hi[t])
         u_new[t] = ctl if kind == "abs" else s_t[n:] + ctl
         x_new[t + 1] = system.dynamics(x_new[t], u_new[t])

@@ -1028,6 +1028,53 @@ def test_quasistatic_example_runner(amd, argv, monkeypatch, capsys):
         assert min(hist[1:]) < hist[0]
 
 
+def test_quasistatic_active_set_warm_start_across_iterations(amd):
+    """irs_quasistatic_box_descent_ws: the active set of the first tail handed from one descent to the
+    next.  Two consecutive iterations of the planar-hand problem (the second linearised around the first
+    one's result): warm and cold start give the same trajectory (the QP's solution does not depend on
+    the start), device == oracle twin for both, and the returned set is what the oracle's first tail
+    converged to."""
+    from irs_mpc_amd import device as dev
+    T = 30
+    sys_d, sys_o, x0, u_trj = _hand_setup(amd, T)
+    idx = sys_o.indices_u_into_x
+    Q, Qd, R = np.diag(HAND_Q), np.diag(100 * HAND_Q), 5.0 * np.eye(4)
+    xd = np.tile(x0 + HAND.pack([0.3, -0.1, 0.5], [0, 0], [0, 0]), (T + 1, 1))
+    ub = np.array([-np.ones(4) * 0.05, np.ones(4) * 0.05])
+    rng = np.random.default_rng(21)
+    dm = sys_d.dm()
+    act_d = dev.to_dev(np.zeros((T, 4)))
+    act_o = np.zeros((T, 4))
+    x_trj = orc.rollout(sys_o, x0, u_trj)
+    for it in (1, 2):
+        du = (0.3 / it ** 0.8) * rng.normal(size=(T, 400, 4))
+        At, Bt, ct = orc.zero_order_B_decoupled(sys_o, x_trj, u_trj, du)
+        rows = orc.quasistatic_bounds(x_trj, idx, None, ub, None)
+        args = [dev.to_dev(a) for a in (At, Bt, ct, Q, Qd, R, xd, x0)]
+        cold = dm.quasistatic_box_descent(*args, u_lo=dev.to_dev(rows[2]), u_hi=dev.to_dev(rows[3]), solver=2,
+                                          max_iter=2000, eps=1e-10)
+        u_cold = cold["u_new"].cpu().numpy().copy()
+        warm = dm.quasistatic_box_descent(*args, u_lo=dev.to_dev(rows[2]), u_hi=dev.to_dev(rows[3]), solver=2,
+                                          max_iter=2000, eps=1e-10, act=act_d)
+        info = warm["info"].cpu().numpy()
+        assert info[0] == 0 and info[2] == 0, info
+        np.testing.assert_allclose(warm["u_new"].cpu().numpy(), u_cold, rtol=0, atol=1e-8)
+        xo, uo, _ = orc.local_descent_quasistatic_as(sys_o, At, Bt, ct, Q, Qd, R, x0, xd, rows[2], rows[3], "abs",
+                                                     act_io=act_o)
+        np.testing.assert_allclose(warm["u_new"].cpu().numpy(), uo, rtol=0, atol=1e-8)
+        np.testing.assert_array_equal(act_d.cpu().numpy(), act_o)
+        assert np.abs(act_o).sum() > 10                  # the trust region binds
+        x_trj, u_trj = xo, uo
+    # garbage in the warm start (and a pin at an infinite bound) is harmless
+    junk = dev.to_dev(rng.integers(-1, 2, size=(T, 4)).astype(np.float64) * 3.0)
+    again = dm.quasistatic_box_descent(*args, u_lo=dev.to_dev(rows[2]), u_hi=dev.to_dev(rows[3]), solver=2,
+                                       max_iter=2000, eps=1e-10, act=junk)
+    np.testing.assert_allclose(again["u_new"].cpu().numpy(), u_cold, rtol=0, atol=1e-8)
+    free = dm.quasistatic_box_descent(*args, solver=2, max_iter=2000, eps=1e-10, act=junk.clone())
+    none = dm.quasistatic_box_descent(*args, solver=2, max_iter=2000, eps=1e-10)
+    np.testing.assert_allclose(free["u_new"].cpu().numpy(), none["u_new"].cpu().numpy(), rtol=0, atol=1e-9)
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_quasistatic_active_set_random_problems(amd, seed):
     """The active-set descent on randomised planar-hand problems (nominal trajectory, goal, bound
