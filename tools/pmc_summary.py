@@ -1,4 +1,5 @@
-"""Condenses the rocprofv3 passes of tools/profile_round.sh into small files for profiles/."""
+"""Condenses the rocprofv3 passes of tools/profile_round.sh into small files for profiles/:
+per-kernel call counts / average durations, and per-kernel averages of every PMC counter."""
 import collections
 import csv
 import glob
@@ -7,31 +8,55 @@ import os
 import sys
 
 out_dir, tag = sys.argv[1], sys.argv[2]
-res = {}
+
+
+def short(name):
+    """Key of the benchmarked kernels: <workload>_<mode>_T.._N.. (bench.py's roofline() looks them up)."""
+    import re
+    m = re.search(r"smooth_kernel<(?:\(anonymous namespace\)::)?(\w+), (\d)", name)
+    if m is None:
+        m = re.search(r"smooth_kernelI\d+(\w+?)Li(\d)E", name)         # mangled
+    if m:
+        model, mode = m.group(1), int(m.group(2))
+        tag = {0: "zero", 1: "first", 2: "zeroB"}[mode]
+        if "PlanarHand" in model:
+            return "planar_hand_%s_T50_N10000" % tag
+        if "Pendulum" in model:
+            return "pendulum_%s_T30_N10000" % tag
+        return None
+    if "ctrlbox_descent_kernel" in name:
+        return "planar_hand_ctrlbox_descent_T50"
+    if "descent_kernel" in name:
+        return "pendulum_descent_T30"
+    return None
+
+
+res = collections.defaultdict(dict)
 lines = []
-for N in (10000, 1000000):
-    key = "pendulum_zero_T30_N%d" % N
-    res[key] = {}
-    # kernel stats
-    f = glob.glob("%s/stats_N%d/*/*kernel_stats.csv" % (out_dir, N))
-    if f:
-        for r in csv.DictReader(open(f[0])):
-            lines.append("N=%d,%s,%s,%s,%s,%s" % (N, r["Name"].replace(",", ";")[:110], r["Calls"], r["AverageNs"], r["MinNs"], r["MaxNs"]))
+f = glob.glob("%s/stats/*/*kernel_stats.csv" % out_dir)
+if f:
+    for r in csv.DictReader(open(f[0])):
+        lines.append("%s,%s,%s,%s,%s" % (r["Name"].replace(",", ";")[:140], r["Calls"], r["AverageNs"], r["MinNs"], r["MaxNs"]))
+        k = short(r["Name"])
+        if k:
+            res[k]["kernel_avg_ns"] = float(r["AverageNs"])
+            res[k]["kernel_calls"] = int(r["Calls"])
             if "smooth_kernel" in r["Name"]:
-                res[key]["smooth_kernel_avg_ns"] = float(r["AverageNs"])
-                res[key]["smooth_kernel_calls"] = int(r["Calls"])
-    for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
-        f = glob.glob("%s/%s_N%d/*/*counter_collection.csv" % (out_dir, sub, N))
-        if not f:
-            continue
-        vals = collections.defaultdict(list)
-        for r in csv.DictReader(open(f[0])):
+                res[k]["smooth_kernel_avg_ns"] = float(r["AverageNs"])
+for d in sorted(glob.glob("%s/pmc_*" % out_dir)):
+    if not os.path.isdir(d):
+        continue
+    ctr = os.path.basename(d)[4:]
+    vals = collections.defaultdict(list)
+    for fn in glob.glob("%s/*/*counter_collection.csv" % d):
+        for r in csv.DictReader(open(fn)):
             if r.get("Counter_Name") == ctr:
                 vals[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-        for k, v in vals.items():
-            if "smooth_kernel" in k:
-                res[key][ctr + "_raw_avg"] = sum(v) / len(v)
-                res[key][ctr + "_n"] = len(v)
+    for name, v in vals.items():
+        k = short(name)
+        if k:
+            res[k][ctr + "_raw_avg"] = sum(v) / len(v)
+            res[k][ctr + "_n"] = len(v)
 json.dump(res, open(os.path.join(out_dir, "pmc_summary.json"), "w"), indent=1)
-open(os.path.join(out_dir, "kernel_stats.csv"), "w").write("workload,kernel,calls,avg_ns,min_ns,max_ns\n" + "\n".join(lines) + "\n")
+open(os.path.join(out_dir, "kernel_stats.csv"), "w").write("kernel,calls,avg_ns,min_ns,max_ns\n" + "\n".join(lines) + "\n")
 print(json.dumps(res, indent=1))

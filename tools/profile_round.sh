@@ -1,17 +1,27 @@
 #!/bin/bash
-# Round profile (run on the GPU box through gpurun).  Produces, under gpurun_out/prof_$TAG:
-#   stats/   rocprofv3 --kernel-trace --stats of `bench.py --steps 100`
-#   fetch/   separate pass: --pmc FETCH_SIZE      write/  separate pass: --pmc WRITE_SIZE
-# for the headline N (default 10000) and for N=1000000 (the HBM-streaming regime).
-TAG=${1:-r01}
+# Round profile of the DEFAULT bench.py run (planar_hand T=50 N=1e4 zero-order-B, its first-order
+# sub-report, the pendulum sub-report), run on the GPU box through gpurun.  Under gpurun_out/prof_$TAG:
+#   stats/           rocprofv3 --kernel-trace --stats of the whole default run
+#   pmc_<COUNTER>/   one separate --pmc pass per counter and per workload (HBM bytes; VALU counters)
+# One workload per profiled process (a --pmc pass over ~50k dispatches in one process segfaulted inside
+# rocprofv3's dispatch interception in an earlier round).
+TAG=${1:-r01g}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for N in 10000 1000000; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_N$N -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --N $N > $OUT/stats_N$N.log 2>&1
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_N$N -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --N $N > $OUT/fetch_N$N.log 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write_N$N -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --N $N > $OUT/write_N$N.log 2>&1
+ARGS="--steps 200 --warmup 20 --no-cpu-baseline"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py $ARGS > $OUT/stats.log 2>&1
+echo "stats rc=$?"
+for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py $ARGS --no-secondary > $OUT/pmc_$C.log 2>&1
+  echo "pass $C (planar_hand zero-order-B) rc=$?"
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py $ARGS --no-secondary --mode first_order > $OUT/pmc_${C}_first.log 2>&1
+  echo "pass $C (planar_hand first-order) rc=$?"
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py --steps 2000 --warmup 200 --no-cpu-baseline --workload pendulum > $OUT/pmc_${C}_pendulum.log 2>&1
+  echo "pass $C (pendulum) rc=$?"
 done
 cd $R
 python tools/pmc_summary.py $OUT $TAG
+# the raw traces are tens of MB (every launch is a row): keep only the summaries
+rm -rf $OUT/stats $OUT/pmc_*/
