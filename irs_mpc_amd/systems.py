@@ -201,7 +201,7 @@ class BoxOnBoxDynamics(QuasistaticDeviceDynamics):
     device contact-QP code as the planar functors and is checked against the closed form there."""
     device_model = MODEL_BOX_ON_BOX
 
-    def __init__(self, h=0.1, m=1.0, k=100.0, pgs_iters=4):
+    def __init__(self, h=0.1, m=1.0, k=100.0, pgs_iters=50):
         super().__init__()
         self.h, self.m, self.k, self.pgs_iters = h, m, k, pgs_iters
         self.dim_x, self.dim_u = 2, 1

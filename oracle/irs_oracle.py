@@ -287,13 +287,15 @@ class _ContactQPOracle:
     """Shared tail of the contact oracles: subclasses provide `_qp(x, u)` -> (Dinv, b, J, phi) in
     their INTERNAL coordinate order and `PERM` (internal index -> index in the reference's x)."""
 
+    PGS_OMEGA = 1.5         # over-relaxation of the projected sweeps (csrc/contact_models.hpp, kContactPgsOmega)
+
     def dynamics_batch(self, x, u):
         Dinv, b, J, phi = self._qp(x, u)
         nc = J.shape[1]
         W = np.einsum("bik,k,bjk->bij", J, Dinv, J)
         r = phi - np.einsum("bik,k,bk->bi", J, Dinv, b)
         lam = np.zeros_like(r)
-        invW = 1.0 / np.einsum("bii->bi", W)
+        invW = self.PGS_OMEGA / np.einsum("bii->bi", W)
         g = r.copy()                               # residual g = r + W lam, kept up to date
         for _ in range(int(self.pgs_iters)):
             for i in range(nc):
@@ -331,7 +333,7 @@ class _ContactQPOracle:
         W = np.einsum("bik,k,bjk->bij", J, Dinv, J)
         r = phi - np.einsum("bik,k,bk->bi", J, Dinv, b)
         lam = np.zeros_like(r)
-        invW = 1.0 / np.einsum("bii->bi", W)
+        invW = self.PGS_OMEGA / np.einsum("bii->bi", W)
         g = r.copy()
         for _ in range(int(self.pgs_iters)):
             for i in range(nc):
