@@ -36,8 +36,9 @@ VALU_F32_PEAK_TFLOPS = 157.3  # peak FP32 (vector), same guide
 class Workload:
     """Everything that differs between the benchmarked configurations."""
 
-    def __init__(self, name, T=None, mode=None, host_only=False):
+    def __init__(self, name, T=None, mode=None, host_only=False, contact_solver="pgs"):
         self.name = name
+        self.contact_solver = contact_solver
         if host_only:           # a CPU-baseline worker process: only what the oracle needs, no GPU library
             self._host_only(T, mode)
             return
@@ -57,7 +58,7 @@ class Workload:
             self.flops_per_sample = None
         elif name == "planar_hand":
             self.T = T or 50
-            self.system = PlanarHandDynamics(0.1)
+            self.system = PlanarHandDynamics(0.1, contact_solver=contact_solver)
             self.mode, self.mode_name = _lib.SMOOTH_ZERO_ORDER_B, "ZERO_ORDER_B"
             # examples/planar_hand/run_planar_hand.py:31-44 (initial grasp), :113-131 (costs, goal)
             sd = self.system
@@ -82,6 +83,11 @@ class Workload:
                 self.label = "planar_hand quasi-dynamic contact, first-order smoothing (per-sample active-set derivative)"
                 self.kernel = "smooth_kernel<PlanarHandModel, FIRST_ORDER>"
                 self.flops_per_sample = 1500 + 152 * int(self.system.pgs_iters) + 1208
+            if contact_solver == "exact":
+                # the dual active-set solve takes a data-dependent number of steps: no fixed flop count
+                self.label += " [step QP solved exactly: dual active-set method]"
+                self.kernel = self.kernel.replace("PlanarHandModel", "PlanarHandExactModel")
+                self.flops_per_sample = None
         else:
             raise ValueError(name)
 
@@ -219,6 +225,8 @@ def main():
     ap.add_argument("--sweep", action="store_true", help="also time N=1e3,1e5,1e6 (extra keys)")
     ap.add_argument("--mode", default=None, choices=["first_order"],
                     help="planar_hand: gradient_mode first_order instead of zero_order_B as the timed workload")
+    ap.add_argument("--contact-solver", default="pgs", choices=["pgs", "exact"],
+                    help="planar_hand: 50 over-relaxed projected sweeps (default) or the exact dual active-set solve")
     ap.add_argument("--no-graph", action="store_true",
                     help="several ranks: issue the step's launches one by one instead of replaying a HIP graph")
     ap.add_argument("--force-unfused", action="store_true",
@@ -481,7 +489,8 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_path):
             tag = {"ZERO_ORDER_AB": "zero", "ZERO_ORDER_B": "zeroB", "FIRST_ORDER": "first"}[w.mode_name]
-            key = "%s_%s_T%d_N%d" % (w.name, tag, w.T, N)
+            key = "%s_%s_T%d_N%d" % (w.name + ("_exact" if getattr(w, "contact_solver", "pgs") == "exact" else ""),
+                                     tag, w.T, N)
             pmc = json.load(open(pmc_path)).get(key)
             if pmc and "FETCH_SIZE_raw_avg" in pmc:
                 traffic = (2.0 * pmc["FETCH_SIZE_raw_avg"] + pmc.get("WRITE_SIZE_raw_avg", 0.0)) * 1024.0
@@ -501,7 +510,7 @@ def main():
                               "vector rate, not HBM or MFMA; the HBM view of the same launch is under 'hbm'"})
         return r
 
-    w = Workload(args.workload, args.T, args.mode)
+    w = Workload(args.workload, args.T, args.mode, contact_solver=args.contact_solver)
     N, T = args.N, w.T
     el, el_it, k_mean, nm, loop = run(w, N, args.steps, args.warmup)
     out = {
@@ -552,6 +561,17 @@ def main():
                               "ms_per_step": 1e3 * e1 / st1, "ilqr_iters_per_s": loop1["iters_per_s"],
                               "ilqr_loop": loop1, "ilqr_first_iter_per_s": st1 / ei1,
                               "roofline": roofline(w1, N, km1, nm1)}
+    if world == 1 and not unfused and not args.no_secondary and w.name == "planar_hand" and args.mode is None \
+            and args.contact_solver == "pgs":
+        # the same workload with the step QP solved exactly (IRS_MODEL_PLANAR_HAND_EXACT)
+        wx = Workload("planar_hand", args.T, None, contact_solver="exact")
+        stx = max(20, args.steps // 4)
+        ex_, eix, kmx, nmx, loopx = run(wx, N, stx, max(1, stx // 10))
+        out["exact_contact_solver"] = {"config": {"workload": wx.label, "T": wx.T, "N_per_gpu": N, "mode": wx.mode_name},
+                                       "value": N * wx.T * stx / ex_, "unit": "rollouts*timesteps/s", "steps": stx,
+                                       "ms_per_step": 1e3 * ex_ / stx, "avg_launch_ms": kmx,
+                                       "ilqr_iters_per_s": loopx["iters_per_s"], "ilqr_loop": loopx,
+                                       "ilqr_first_iter_per_s": stx / eix}
     if world == 1 and not unfused and not args.no_secondary and w.name != "pendulum":
         w2 = Workload("pendulum")
         st2 = 10000

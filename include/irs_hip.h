@@ -72,6 +72,9 @@ typedef enum irs_model_id {
                                  box_pivoting seen from above (no gravity, no ground, Kp = 500); x, u as there;
                                  params = {h, mass, inertia, half, mu, kp, r_hand, pgs_iters}.  PINNED by the
                                  simulator data examples/box_pushing/analysis/{xu,dxdu}_quasistatic.npy        */
+    , IRS_MODEL_PLANAR_HAND_EXACT = 8 /* IRS_MODEL_PLANAR_HAND with the step QP solved EXACTLY (dual active-set
+                                 method, csrc/contact_models.hpp) -- what the reference's simulator does (Gurobi) --
+                                 instead of by pgs_iters projected sweeps; same params (pgs_iters ignored)      */
 } irs_model_id;
 
 /* Smoothing estimators.                                                         */

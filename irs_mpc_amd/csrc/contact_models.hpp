@@ -108,6 +108,169 @@ IRS_HD void irs_contact_qp_dual(const typename scalar_of<S>::type* Dinv, const S
     }
 }
 
+// ---- EXACT dual solve: the Goldfarb-Idnani dual active-set method written in the dual variables --------
+// The primal QP has the diagonal Hessian D, so the Schur complement of an active set A is W_AA.  Start from
+// lam = 0 (the unconstrained primal optimum) and repeat: p = the most violated row (slack g_p = (r + W lam)_p
+// < 0) outside A; step along  d lam_A = -rho, d lam_p = +1,  rho = W_AA^-1 W_Ap  -- the active slacks stay at
+// zero, g_p rises at rate z = W_pp - W_pA rho -- until g_p = 0 (full step: p joins A) or some lam_i in A
+// reaches zero first (partial step: i leaves A, p stays the candidate).  z = 0 marks a row that depends on
+// A: only partial steps are possible.  Every step increases the dual objective: finite, no cycling, no
+// regularisation; dependent rows never enter A, so W_AA stays positive definite.  (Projected sweeps crawl on
+// exactly these problems: W is near-singular when several contacts load one body -- DESIGN.md 7.)
+// SIMT form: no lane ever indexes a register array by a run-time value -- the candidate row and the
+// blocking row are one-hot vectors, the factorisation of W_AA is the masked LDL' of irs_contact_qp_grad --
+// and the loop is wave-uniform: it ends when every lane of the wave is done (cap 4 NC steps; a lane that
+// hits the cap keeps its last multipliers, which are dual feasible).  Restated in oracle/irs_oracle.py
+// (_ContactQPOracle._dual_exact).  T = float or double.
+template <typename T>
+IRS_HD bool irs_wave_all(bool v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __all(v);
+#else
+    return v;
+#endif
+}
+
+template <typename T, int NX, int NC>
+IRS_HD void irs_contact_qp_dual_exact(const T* Dinv, const T* b, const T (*J)[NX], const T* phi, T (*W)[NC],
+                                      T* lam) {
+    constexpr T kBig = T(3.0e38);
+    const T tol_rel = sizeof(T) == 4 ? T(1e-6) : T(1e-10);
+    const T piv_rel = sizeof(T) == 4 ? T(1e-5) : T(1e-7);
+    T g[NC], Wd[NC];
+    bool act[NC];
+    {
+        T JD[NC][NX], Db[NX];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) Db[k] = b[k] * Dinv[k];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) JD[i][k] = J[i][k] * Dinv[k];
+            T ri = phi[i];
+#pragma unroll
+            for (int k = 0; k < NX; ++k) ri = ri - J[i][k] * Db[k];
+            g[i] = ri;
+            lam[i] = T(0);
+            act[i] = false;
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                T w = JD[i][0] * J[j][0];
+#pragma unroll
+                for (int k = 1; k < NX; ++k) w = w + JD[i][k] * J[j][k];
+                W[i][j] = w;
+                W[j][i] = w;
+            }
+            Wd[i] = W[i][i];
+        }
+    }
+    T scale = T(1e-30);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) scale = fmax(scale, fabs(g[i]));
+    const T tolv = tol_rel * scale;
+    int p = -1;                    // candidate row, -1 = none
+    bool done = false;
+    for (int it = 0; it < 4 * NC; ++it) {
+        if (!done && p < 0) {
+            T vmin = kBig;
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                const T v = act[i] ? kBig : g[i];
+                if (v < vmin) { vmin = v; c = i; }
+            }
+            if (vmin >= -tolv) done = true;
+            else p = c;
+        }
+        if (irs_wave_all<T>(done)) break;
+        // candidate row as a one-hot vector; its column of W, its diagonal entry and its slack
+        T e[NC], wp[NC];
+        T wpp = T(0), gp = T(0);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) e[i] = (!done && i == p) ? T(1) : T(0);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            T s = T(0);
+#pragma unroll
+            for (int j = 0; j < NC; ++j) s = s + W[i][j] * e[j];
+            wp[i] = s;
+            wpp = wpp + Wd[i] * e[i];
+            gp = gp + g[i] * e[i];
+        }
+        // rho = W_AA^-1 W_Ap: masked LDL' in row order on a copy (unit lower factor in the upper triangle)
+        T M_[NC][NC], inv[NC], rho[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) M_[i][j] = W[i][j];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const T dj = M_[j][j];
+            const bool ok = act[j] && dj > piv_rel * Wd[j];
+            inv[j] = ok ? T(1) / dj : T(0);
+#pragma unroll
+            for (int i = j + 1; i < NC; ++i) M_[j][i] = M_[i][j] * inv[j];
+#pragma unroll
+            for (int i = j + 1; i < NC; ++i)
+#pragma unroll
+                for (int k = j + 1; k <= i; ++k) M_[i][k] = M_[i][k] - M_[j][i] * M_[k][j];
+        }
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            T y = act[j] ? wp[j] : T(0);
+#pragma unroll
+            for (int k = 0; k < j; ++k) y = y - M_[k][j] * rho[k];
+            rho[j] = y;
+        }
+#pragma unroll
+        for (int j = NC - 1; j >= 0; --j) {
+            T y = rho[j] * inv[j];
+#pragma unroll
+            for (int i = j + 1; i < NC; ++i) y = y - M_[j][i] * rho[i];
+            rho[j] = y;
+        }
+        // step lengths
+        T zp = wpp;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) zp = zp - (act[i] ? wp[i] * rho[i] : T(0));
+        const bool full_ok = zp > piv_rel * wpp;
+        const T t2 = full_ok ? -gp / zp : kBig;
+        T t1 = kBig;
+        int kb = 0;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const bool cand = act[i] && rho[i] > T(0);
+            const T q = cand ? lam[i] / rho[i] : kBig;
+            if (q < t1) { t1 = q; kb = i; }
+        }
+        const T tmin = fmin(t1, t2);
+        if (!done && !(tmin < kBig)) done = true;          // no step possible: infeasible primal, keep lam
+        const T t = done ? T(0) : tmin;
+        // lam_A -= t rho, lam_p += t, g += t (W_p - W rho)
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            T s = wp[i];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) s = s - W[i][j] * rho[j];
+            g[i] = g[i] + t * s;
+            lam[i] = fmax(lam[i] - t * rho[i] + t * e[i], T(0));
+        }
+        if (!done) {
+            const bool full = t2 <= t1;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                if (full) {
+                    if (i == p) act[i] = true;
+                } else if (i == kb) {
+                    act[i] = false;
+                    lam[i] = T(0);
+                }
+            }
+            if (full) p = -1;
+        }
+    }
+}
+
 template <typename S, int NX, int NC>
 IRS_HD void irs_contact_qp_primal(const S* q, const typename scalar_of<S>::type* Dinv, const S* b,
                                   const S (*J)[NX], const S* lam, S* qn) {
@@ -219,6 +382,12 @@ IRS_HD void irs_contact_qp_grad(const T* Dinv, const T (*J)[NX], T (*W)[NC], con
     }
 }
 
+// contact models with `static constexpr bool EXACT = true` solve the step QP exactly (irs_contact_qp_dual_exact)
+template <class M, class = void>
+struct irs_contact_exact : std::false_type {};
+template <class M>
+struct irs_contact_exact<M, std::void_t<decltype(M::EXACT)>> : std::integral_constant<bool, M::EXACT> {};
+
 // One step of contact model M (its `assemble` builds the QP in the internal coordinate order).
 template <class M, typename S>
 IRS_HD void irs_contact_step(const ModelParams& p, const S* x_ext, const S* u, S* xn_ext) {
@@ -227,7 +396,13 @@ IRS_HD void irs_contact_step(const ModelParams& p, const S* x_ext, const S* u, S
     S q[NX], qn[NX], b[NX], J[NC][NX], phi[NC];
     T Dinv[NX];
     const int iters = M::template assemble<S>(p, x_ext, u, q, Dinv, b, J, phi);
-    irs_contact_qp_step<S, NX, NC>(q, Dinv, b, J, phi, iters, qn);
+    if constexpr (irs_contact_exact<M>::value) {
+        S W[NC][NC], lam[NC];
+        irs_contact_qp_dual_exact<S, NX, NC>(Dinv, b, J, phi, W, lam);
+        irs_contact_qp_primal<S, NX, NC>(q, Dinv, b, J, lam, qn);
+    } else {
+        irs_contact_qp_step<S, NX, NC>(q, Dinv, b, J, phi, iters, qn);
+    }
 #pragma unroll
     for (int k = 0; k < NX; ++k) xn_ext[M::perm(k)] = qn[k];
 }
@@ -239,7 +414,8 @@ IRS_HD void irs_contact_step_grad(const ModelParams& p, const T* x_ext, const T*
     constexpr int NX = M::NX, NC = M::NC, NU = M::NU;
     T q[NX], qn[NX], b[NX], J[NC][NX], phi[NC], Dinv[NX], W[NC][NC], lam[NC];
     const int iters = M::template assemble<T>(p, x_ext, u, q, Dinv, b, J, phi);
-    irs_contact_qp_dual<T, NX, NC>(Dinv, b, J, phi, iters, W, lam);
+    if constexpr (irs_contact_exact<M>::value) irs_contact_qp_dual_exact<T, NX, NC>(Dinv, b, J, phi, W, lam);
+    else irs_contact_qp_dual<T, NX, NC>(Dinv, b, J, phi, iters, W, lam);
     irs_contact_qp_primal<T, NX, NC>(q, Dinv, b, J, lam, qn);
 #pragma unroll
     for (int k = 0; k < NX; ++k) xn_ext[M::perm(k)] = qn[k];
@@ -364,6 +540,17 @@ struct PlanarHandModel {
     }
 };
 
+
+// The planar hand with its step QP solved EXACTLY (irs_contact_qp_dual_exact) instead of by `pgs_iters`
+// sweeps; same parameters (pgs_iters is ignored).  A separate model id so that the kernels of the
+// sweep-based functor -- the benchmarked ones -- are not touched by the extra code path.
+struct PlanarHandExactModel : PlanarHandModel {
+    static constexpr bool EXACT = true;
+    template <typename S>
+    IRS_HD static void step(const ModelParams& p, const S* x_ext, const S* u, S* xn_ext) {
+        irs_contact_step<PlanarHandExactModel, S>(p, x_ext, u, xn_ext);
+    }
+};
 
 // Rows of a disc ("hand", radius rh, centre (q[3], q[4])) against a square box (half side a, centre
 // (q[0], q[1]), angle q[2]; sn, cs = sin / cos of the angle): two friction-cone generators n +- mu t of

@@ -290,18 +290,7 @@ class _ContactQPOracle:
     PGS_OMEGA = 1.5         # over-relaxation of the projected sweeps (csrc/contact_models.hpp, kContactPgsOmega)
 
     def dynamics_batch(self, x, u):
-        Dinv, b, J, phi = self._qp(x, u)
-        nc = J.shape[1]
-        W = np.einsum("bik,k,bjk->bij", J, Dinv, J)
-        r = phi - np.einsum("bik,k,bk->bi", J, Dinv, b)
-        lam = np.zeros_like(r)
-        invW = self.PGS_OMEGA / np.einsum("bii->bi", W)
-        g = r.copy()                               # residual g = r + W lam, kept up to date
-        for _ in range(int(self.pgs_iters)):
-            for i in range(nc):
-                new = np.maximum(lam[:, i] - g[:, i] * invW[:, i], 0.0)
-                g += W[:, :, i] * (new - lam[:, i])[:, None]
-                lam[:, i] = new
+        Dinv, b, J, W, lam = self._pgs(np.atleast_2d(x), np.atleast_2d(u))
         out = np.array(np.atleast_2d(x), dtype=float)
         out[:, self.PERM] += (np.einsum("bik,bi->bk", J, lam) - b) * Dinv
         return out
@@ -327,11 +316,97 @@ class _ContactQPOracle:
     ACTIVE_TOL = 1e-7       # a contact row is active when lam_i W_ii (a length) exceeds this
     PIVOT_TOL = 1e-5        # an active row whose pivot falls below PIVOT_TOL * W_ii is dependent: dropped
 
+    # `pgs_iters <= 0` selects the EXACT dual solve (device: the *_EXACT model ids) instead of sweeps
+    EXACT_TOL = 1e-10       # constraint violation (relative to max |r|) below which the dual solve stops
+    EXACT_PIVOT = 1e-7      # a candidate row whose Schur complement is below this (relative) is dependent
+
+    @staticmethod
+    def _masked_solve(W, rhs, A, piv):
+        """W_AA y_A = rhs_A by the masked LDL' in row order (y = 0 outside A); batched."""
+        Bn, nc, _ = W.shape
+        Wm, L, inv = W.copy(), np.zeros_like(W), np.zeros((Bn, nc))
+        Wd = np.einsum("bii->bi", W)
+        for j in range(nc):
+            dj = Wm[:, j, j]
+            ok = A[:, j] & (dj > piv * Wd[:, j])
+            inv[:, j] = np.where(ok, 1.0 / np.where(ok, dj, 1.0), 0.0)
+            for i in range(j + 1, nc):
+                L[:, i, j] = Wm[:, i, j] * inv[:, j]
+            for i in range(j + 1, nc):
+                for k in range(j + 1, i + 1):
+                    Wm[:, i, k] -= L[:, i, j] * Wm[:, k, j]
+        y = np.where(A, rhs, 0.0)
+        for j in range(nc):
+            for k in range(j):
+                y[:, j] -= L[:, j, k] * y[:, k]
+        y *= inv
+        for j in range(nc - 1, -1, -1):
+            for i in range(j + 1, nc):
+                y[:, j] -= L[:, i, j] * y[:, i]
+        return y
+
+    def _dual_exact(self, W, r):
+        """min 1/2 lam'W lam + r'lam, lam >= 0, solved EXACTLY by the Goldfarb-Idnani dual active-set method
+        written in the dual variables (the primal QP has the diagonal Hessian D, so its active-set Schur
+        complement is W_AA): start from lam = 0 (the unconstrained primal optimum); repeat: p = the most
+        violated row (slack g_p = (r + W lam)_p < 0) outside the active set A; step along
+        d lam_A = -rho, d lam_p = +1 with rho = W_AA^-1 W_Ap -- this keeps the active slacks at zero and
+        raises g_p at rate z = W_pp - W_pA rho -- until g_p = 0 (full step: p joins A) or some lam_i in A
+        reaches zero first (partial step: i leaves A; p stays the candidate).  z = 0 marks a row that
+        depends on A: only partial steps are possible.  Every step increases the dual objective: finite, no
+        cycling, no regularisation; dependent rows never enter A, so W_AA stays positive definite.
+        What the device runs for the *_EXACT contact models (csrc/contact_models.hpp)."""
+        Bn, nc, _ = W.shape
+        ar = np.arange(Bn)
+        Wd = np.einsum("bii->bi", W)
+        A = np.zeros((Bn, nc), bool)
+        lam, g = np.zeros((Bn, nc)), r.copy()
+        p = np.full(Bn, -1)
+        done = np.zeros(Bn, bool)
+        tolv = self.EXACT_TOL * (np.abs(r).max(1) + 1e-300)
+        for _ in range(4 * nc):
+            need = (p < 0) & ~done
+            viol = np.where(A, np.inf, g)
+            cand = np.argmin(viol, 1)
+            fin = need & (viol[ar, cand] >= -tolv)
+            done |= fin
+            p = np.where(need & ~fin, cand, p)
+            live = ~done
+            if not live.any():
+                break
+            pp = np.where(p >= 0, p, 0)
+            Wp = W[ar, :, pp]
+            rho = self._masked_solve(W, Wp, A, self.EXACT_PIVOT)
+            zp = Wd[ar, pp] - np.einsum("bi,bi->b", np.where(A, Wp, 0.0), rho)
+            full_ok = zp > self.EXACT_PIVOT * Wd[ar, pp]
+            t2 = np.where(full_ok, -g[ar, pp] / np.where(full_ok, zp, 1.0), np.inf)
+            ratio = np.where(A & (rho > 0), lam / np.where(rho > 0, rho, 1.0), np.inf)
+            k = np.argmin(ratio, 1)
+            t1 = ratio[ar, k]
+            t = np.minimum(t1, t2)
+            stuck = live & ~np.isfinite(t)            # infeasible primal: keep the current multipliers
+            done |= stuck
+            live &= ~stuck
+            tt = np.where(live & np.isfinite(t), t, 0.0)
+            lam = lam - tt[:, None] * rho
+            lam[ar, pp] += tt
+            g = g + tt[:, None] * (Wp - np.einsum("bij,bj->bi", W, rho))
+            full = live & (t2 <= t1)
+            part = live & ~(t2 <= t1)
+            A[ar[full], pp[full]] = True
+            p = np.where(full, -1, p)
+            A[ar[part], k[part]] = False
+            lam[ar[part], k[part]] = 0.0
+            lam = np.maximum(lam, 0.0)
+        return lam
+
     def _pgs(self, x, u):
         Dinv, b, J, phi = self._qp(x, u)
         nc = J.shape[1]
         W = np.einsum("bik,k,bjk->bij", J, Dinv, J)
         r = phi - np.einsum("bik,k,bk->bi", J, Dinv, b)
+        if int(self.pgs_iters) <= 0:
+            return Dinv, b, J, W, self._dual_exact(W, r)
         lam = np.zeros_like(r)
         invW = self.PGS_OMEGA / np.einsum("bii->bi", W)
         g = r.copy()

@@ -804,6 +804,46 @@ def test_planar_hand_first_order_decoupled_vs_oracle(amd):
     assert np.abs(o2["Bt"].cpu().numpy() - Bt).max() < 0.1
 
 
+def test_planar_hand_exact_contact_solver_vs_oracle(amd):
+    """contact_solver="exact" (IRS_MODEL_PLANAR_HAND_EXACT): the device's dual active-set solve of the step QP
+    == the oracle's (`pgs_iters = 0`) in f64 (dynamics, active-set Jacobian), and through the f32 sample
+    pass in both estimators, on the heavily loaded samples where 50 sweeps are off by up to 5e-2."""
+    from irs_mpc_amd import device as dev
+    from irs_mpc_amd._lib import SMOOTH_FIRST_ORDER, SMOOTH_ZERO_ORDER_B
+    T, N = 6, 2000
+    sys_o = orc.PlanarHandOracle(0.1, pgs_iters=0)
+    sys_d = amd.PlanarHandDynamics(0.1, contact_solver="exact")
+    pgs_d = amd.PlanarHandDynamics(0.1)
+    x0 = HAND.pack([0.0, 0.35, 0.0], [-np.pi / 4, -np.pi / 4], [np.pi / 4, np.pi / 4])
+    u_trj = np.tile(x0[HAND_IDX], (T, 1))
+    x_trj = orc.rollout(sys_o, x0, u_trj)
+    np.testing.assert_allclose(sys_d.dm().rollout_cost(dev.to_dev(x0), dev.to_dev(u_trj), dev.to_dev(np.eye(7)),
+                                                       dev.to_dev(np.eye(4)), dev.to_dev(np.zeros((T + 1, 7))))[0]
+                               .cpu().numpy(), x_trj, rtol=0, atol=1e-9)
+    rng = np.random.default_rng(31)
+    X = np.tile(x_trj[-1], (512, 1)) + 0.01 * rng.normal(size=(512, 7))
+    U = u_trj[-1] + 0.3 * rng.normal(size=(512, 4))
+    want = sys_o.dynamics_batch(X, U)
+    np.testing.assert_allclose(sys_d.dynamics_batch(X, U), want, rtol=0, atol=1e-8)
+    assert np.abs(pgs_d.dynamics_batch(X, U) - want).max() > 1e-4          # the sweeps are not there yet
+    np.testing.assert_allclose(sys_d.jacobian_xu_batch(X, U), sys_o.jacobian_xu_batch(X, U), rtol=0, atol=1e-6)
+    du = (0.3 * rng.normal(size=(T, N, 4))).astype(np.float32)
+    dm = sys_d.dm()
+    xd, ud = dev.to_dev(x_trj), dev.to_dev(u_trj)
+    o = dm.smooth(SMOOTH_ZERO_ORDER_B, xd, ud, None, dev.to_dev(du, dev.F32))
+    assert int(o["info"].abs().sum().item()) == 0
+    Ao, Bo, co = orc.zero_order_B_decoupled(sys_o, x_trj, u_trj, du.astype(np.float64))
+    np.testing.assert_allclose(o["At"].cpu().numpy(), Ao, rtol=0, atol=0)
+    np.testing.assert_allclose(o["Bt"].cpu().numpy(), Bo, rtol=0, atol=3e-4)      # f32 lanes vs the f64 oracle
+    np.testing.assert_allclose(o["ct"].cpu().numpy(), co, rtol=0, atol=3e-4)
+    o1 = dm.smooth(SMOOTH_FIRST_ORDER, xd, ud, None, dev.to_dev(du, dev.F32))
+    _, B1, c1 = orc.first_order_B_decoupled(sys_o, x_trj, u_trj, du.astype(np.float64))
+    np.testing.assert_allclose(o1["Bt"].cpu().numpy(), B1, rtol=0, atol=3e-3)     # borderline rows: O(1)/N each
+    np.testing.assert_allclose(o1["ct"].cpu().numpy(), c1, rtol=0, atol=3e-3)
+    with pytest.raises(ValueError):
+        amd.PlanarHandDynamics(0.1, contact_solver="nope")
+
+
 def test_planar_hand_descent_runs(amd):
     """smooth -> Riccati -> closed-loop rollout through the contact functor in f64 == oracle."""
     from irs_mpc_amd import device as dev
