@@ -122,6 +122,17 @@ IRS_HD void irs_contact_qp_dual(const typename scalar_of<S>::type* Dinv, const S
 // and the loop is wave-uniform: it ends when every lane of the wave is done (cap 4 NC steps; a lane that
 // hits the cap keeps its last multipliers, which are dual feasible).  Restated in oracle/irs_oracle.py
 // (_ContactQPOracle._dual_exact).  T = float or double.
+// 1/x: the hardware estimate (1 ulp) for f32 lanes, a true divide otherwise -- the dual active-set loop divides
+// 2 NC times per step, and a correctly rounded f32 divide is ~10 instructions
+IRS_HD float irs_rcp_fast(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+IRS_HD double irs_rcp_fast(double x) { return 1.0 / x; }
+
 template <typename T>
 IRS_HD bool irs_wave_all(bool v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -207,7 +218,7 @@ IRS_HD void irs_contact_qp_dual_exact(const T* Dinv, const T* b, const T (*J)[NX
         for (int j = 0; j < NC; ++j) {
             const T dj = M_[j][j];
             const bool ok = act[j] && dj > piv_rel * Wd[j];
-            inv[j] = ok ? T(1) / dj : T(0);
+            inv[j] = ok ? irs_rcp_fast(dj) : T(0);
 #pragma unroll
             for (int i = j + 1; i < NC; ++i) M_[j][i] = M_[i][j] * inv[j];
 #pragma unroll
@@ -234,13 +245,13 @@ IRS_HD void irs_contact_qp_dual_exact(const T* Dinv, const T* b, const T (*J)[NX
 #pragma unroll
         for (int i = 0; i < NC; ++i) zp = zp - (act[i] ? wp[i] * rho[i] : T(0));
         const bool full_ok = zp > piv_rel * wpp;
-        const T t2 = full_ok ? -gp / zp : kBig;
+        const T t2 = full_ok ? -gp * irs_rcp_fast(zp) : kBig;
         T t1 = kBig;
         int kb = 0;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const bool cand = act[i] && rho[i] > T(0);
-            const T q = cand ? lam[i] / rho[i] : kBig;
+            const T q = cand ? lam[i] * irs_rcp_fast(rho[i]) : kBig;
             if (q < t1) { t1 = q; kb = i; }
         }
         const T tmin = fmin(t1, t2);
