@@ -11,21 +11,22 @@ out_dir, tag = sys.argv[1], sys.argv[2]
 
 
 def short(name):
-    """Key of the benchmarked kernels: <workload>_<mode>_T.._N.. (bench.py's roofline() looks them up)."""
+    """Key of the benchmarked kernels: <workload>[_exact]_<mode>[_rng][_unfused]_T.._N.. (bench.py's roofline()
+    looks up the supplied-samples, fused variants; the device-RNG variants are the ones of the iLQR loop)."""
     import re
-    m = re.search(r"smooth_kernel<(?:\(anonymous namespace\)::)?(\w+), (\d)", name)
-    if m is None:
-        m = re.search(r"smooth_kernelI\d+(\w+?)Li(\d)E", name)         # mangled
+    m = re.search(r"smooth_kernel<(?:\(anonymous namespace\)::)?(\w+)[,;] (\d)[,;] (true|false)[,;] (true|false)", name)
     if m:
-        model, mode = m.group(1), int(m.group(2))
-        tag = {0: "zero", 1: "first", 2: "zeroB"}[mode]
+        model, mode, rng, fuse = m.group(1), int(m.group(2)), m.group(3) == "true", m.group(4) == "true"
+        tag = {0: "zero", 1: "first", 2: "zeroB"}[mode] + ("_rng" if rng else "") + ("" if fuse else "_unfused")
+        if "PlanarHandExact" in model:
+            return "planar_hand_exact_%s_T50_N10000" % tag
         if "PlanarHand" in model:
             return "planar_hand_%s_T50_N10000" % tag
         if "Pendulum" in model:
             return "pendulum_%s_T30_N10000" % tag
         return None
     if "ctrlbox_descent_kernel" in name:
-        return "planar_hand_ctrlbox_descent_T50"
+        return "planar_hand_exact_ctrlbox_descent_T50" if "PlanarHandExact" in name else "planar_hand_ctrlbox_descent_T50"
     if "descent_kernel" in name:
         return "pendulum_descent_T30"
     return None
