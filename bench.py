@@ -73,8 +73,9 @@ class Workload:
             self.label = "planar_hand quasi-dynamic contact, zero-order-B smoothing (the metric's config)"
             self.kernel = "smooth_kernel<PlanarHandModel, ZERO_ORDER_B>"
             # per one-step evaluation of the contact QP (csrc/contact_models.hpp):
-            # QP assembly ~1.5 kFLOP + 152 FLOP per PGS sweep + the Gram update
-            self.flops_per_sample = 1500 + 152 * int(self.system.pgs_iters) + 76
+            # QP assembly ~1.5 kFLOP + 152 FLOP per projected sweep + the active-set polish (masked LDL' 196,
+            # one solve 120, W dl 128, tests ~26) + the Gram update
+            self.flops_per_sample = 1500 + 152 * int(self.system.pgs_iters) + 470 + 76
             if mode == "first_order":
                 # gradient_mode "first_order" (examples/planar_hand/planar_hand_setup.py:28): every sample's
                 # step is differentiated through its active constraints inside the sample pass -- masked
@@ -82,7 +83,7 @@ class Workload:
                 self.mode, self.mode_name = _lib.SMOOTH_FIRST_ORDER, "FIRST_ORDER"
                 self.label = "planar_hand quasi-dynamic contact, first-order smoothing (per-sample active-set derivative)"
                 self.kernel = "smooth_kernel<PlanarHandModel, FIRST_ORDER>"
-                self.flops_per_sample = 1500 + 152 * int(self.system.pgs_iters) + 1208
+                self.flops_per_sample = 1500 + 152 * int(self.system.pgs_iters) + 470 + 1208
             if contact_solver == "exact":
                 # the dual active-set solve takes a data-dependent number of steps: no fixed flop count
                 self.label += " [step QP solved exactly: dual active-set method]"

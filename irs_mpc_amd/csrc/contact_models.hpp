@@ -43,6 +43,78 @@ IRS_HD S irs_max0(const S& a) { return irs_value(a) > 0 ? a : S(a * (typename sc
 // std 0.3 the 90th percentile drops 10-40x.  Free: the factor is folded into 1 / W_ii.
 constexpr double kContactPgsOmega = 1.5;
 
+// 1/x: the hardware estimate (1 ulp) for f32 lanes, a true divide otherwise -- the dual active-set loop divides
+// 2 NC times per step, and a correctly rounded f32 divide is ~10 instructions
+IRS_HD float irs_rcp_fast(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+IRS_HD double irs_rcp_fast(double x) { return 1.0 / x; }
+
+// Active-set polish after the sweeps.  The sweeps identify the active set I = {lam_i > 0} long before they
+// converge on it (W is near-singular when several contacts load one body); one exact solve ON that set,
+// lam_I += -W_II^-1 g_I (masked LDL' in row order, as in irs_contact_qp_grad), lands on the QP's optimum
+// whenever I is right.  It is accepted only if it is the optimum -- multipliers >= 0 on I, slacks >= 0 off
+// I, the active slacks solved to zero -- otherwise the swept multipliers stand.  Measured on the planar
+// hand (50 sweeps, omega 1.5): 96-99.6 % of the samples accepted and then exact to rounding;
+// the share that is more than 1e-5 off the exactly solved QP falls from 14-32 % to 0.4-4 %.
+template <typename T, int NC>
+IRS_HD void irs_contact_qp_polish(const T (*W)[NC], const T* r, const T* g, T* lam) {
+    const T tol_rel = T(1e-6);
+    const T piv_rel = sizeof(T) == 4 ? T(1e-5) : T(1e-7);
+    T M_[NC][NC], inv[NC], dl[NC];
+    bool in[NC];
+    T scale = T(1e-30);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        in[i] = lam[i] > T(0);
+        scale = fmax(scale, fabs(r[i]));
+#pragma unroll
+        for (int j = 0; j <= i; ++j) M_[i][j] = W[i][j];
+    }
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const T dj = M_[j][j];
+        const bool piv = dj > piv_rel * W[j][j];
+        ok = ok && (piv || !in[j]);                       // a dependent row in I: no polish
+        inv[j] = (in[j] && piv) ? irs_rcp_fast(dj) : T(0);
+#pragma unroll
+        for (int i = j + 1; i < NC; ++i) M_[j][i] = M_[i][j] * inv[j];
+#pragma unroll
+        for (int i = j + 1; i < NC; ++i)
+#pragma unroll
+            for (int k = j + 1; k <= i; ++k) M_[i][k] = M_[i][k] - M_[j][i] * M_[k][j];
+    }
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        T y = in[j] ? -g[j] : T(0);
+#pragma unroll
+        for (int k = 0; k < j; ++k) y = y - M_[k][j] * dl[k];
+        dl[j] = y;
+    }
+#pragma unroll
+    for (int j = NC - 1; j >= 0; --j) {
+        T y = dl[j] * inv[j];
+#pragma unroll
+        for (int i = j + 1; i < NC; ++i) y = y - M_[j][i] * dl[i];
+        dl[j] = y;
+    }
+    const T tolv = tol_rel * scale;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        T gn = g[i];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) gn = gn + W[i][j] * dl[j];
+        ok = ok && (in[i] ? (lam[i] + dl[i] >= T(0) && fabs(gn) <= tolv) : gn >= -tolv);
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) lam[i] = ok ? (in[i] ? lam[i] + dl[i] : T(0)) : lam[i];
+}
+
 template <typename S, int NX, int NC>
 IRS_HD void irs_contact_qp_dual(const typename scalar_of<S>::type* Dinv, const S* b, const S (*J)[NX],
                                 const S* phi, int iters, S (*W)[NC], S* lam) {
@@ -91,6 +163,16 @@ IRS_HD void irs_contact_qp_dual(const typename scalar_of<S>::type* Dinv, const S
                 for (int k = 0; k < NC / 2; ++k) g2[k] = Wc[i][k] * d2 + g2[k];
             }
         }
+        // the polish reads W back out of the packed copy the sweeps used, so that W itself need not stay in
+        // registers across them (a caller that has no further use for W then never holds both)
+        float g[NC], Wl[NC][NC];
+#pragma unroll
+        for (int k = 0; k < NC / 2; ++k) { g[2 * k] = g2[k].x; g[2 * k + 1] = g2[k].y; }
+#pragma unroll
+        for (int a = 0; a < NC; ++a)
+#pragma unroll
+            for (int i = 0; i < NC; ++i) Wl[a][i] = (a & 1) ? Wc[i][a / 2].y : Wc[i][a / 2].x;
+        irs_contact_qp_polish<float, NC>(Wl, r, g, lam);
     } else {
         S g[NC];
 #pragma unroll
@@ -105,6 +187,7 @@ IRS_HD void irs_contact_qp_dual(const typename scalar_of<S>::type* Dinv, const S
                 for (int j = 0; j < NC; ++j) g[j] = g[j] + W[j][i] * dl;
             }
         }
+        if constexpr (std::is_arithmetic<S>::value) irs_contact_qp_polish<S, NC>(W, r, g, lam);
     }
 }
 
@@ -122,17 +205,6 @@ IRS_HD void irs_contact_qp_dual(const typename scalar_of<S>::type* Dinv, const S
 // and the loop is wave-uniform: it ends when every lane of the wave is done (cap 4 NC steps; a lane that
 // hits the cap keeps its last multipliers, which are dual feasible).  Restated in oracle/irs_oracle.py
 // (_ContactQPOracle._dual_exact).  T = float or double.
-// 1/x: the hardware estimate (1 ulp) for f32 lanes, a true divide otherwise -- the dual active-set loop divides
-// 2 NC times per step, and a correctly rounded f32 divide is ~10 instructions
-IRS_HD float irs_rcp_fast(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_rcpf(x);
-#else
-    return 1.0f / x;
-#endif
-}
-IRS_HD double irs_rcp_fast(double x) { return 1.0 / x; }
-
 template <typename T>
 IRS_HD bool irs_wave_all(bool v) {
 #if defined(__HIP_DEVICE_COMPILE__)

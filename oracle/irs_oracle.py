@@ -415,7 +415,36 @@ class _ContactQPOracle:
                 new = np.maximum(lam[:, i] - g[:, i] * invW[:, i], 0.0)
                 g += W[:, :, i] * (new - lam[:, i])[:, None]
                 lam[:, i] = new
-        return Dinv, b, J, W, lam
+        return Dinv, b, J, W, self._polish(W, r, g, lam)
+
+    POLISH_TOL = 1e-6
+
+    def _polish(self, W, r, g, lam):
+        """Active-set polish after the sweeps (csrc/contact_models.hpp, irs_contact_qp_polish): one exact solve
+        on the swept active set I = {lam_i > 0}, lam_I += -W_II^-1 g_I, accepted only if it IS the optimum
+        (multipliers >= 0 on I, slacks >= 0 off I, active slacks solved to zero, no dependent row in I)."""
+        Bn, nc, _ = W.shape
+        I = lam > 0
+        Wd = np.einsum("bii->bi", W)
+        # dependent rows in I (pivot below EXACT_PIVOT W_ii): reject
+        Wm = W.copy()
+        dep = np.zeros(Bn, bool)
+        L = np.zeros_like(W)
+        for j in range(nc):
+            dj = Wm[:, j, j]
+            piv = dj > self.EXACT_PIVOT * Wd[:, j]
+            dep |= I[:, j] & ~piv
+            invj = np.where(I[:, j] & piv, 1.0 / np.where(piv, dj, 1.0), 0.0)
+            for i in range(j + 1, nc):
+                L[:, i, j] = Wm[:, i, j] * invj
+            for i in range(j + 1, nc):
+                for k in range(j + 1, i + 1):
+                    Wm[:, i, k] -= L[:, i, j] * Wm[:, k, j]
+        dl = self._masked_solve(W, -g, I, self.EXACT_PIVOT)
+        gn = g + np.einsum("bij,bj->bi", W, dl)
+        tolv = self.POLISH_TOL * (np.abs(r).max(1, keepdims=True) + 1e-30)
+        ok = ~dep & np.where(I, (lam + dl >= 0) & (np.abs(gn) <= tolv), gn >= -tolv).all(1)
+        return np.where(ok[:, None], np.where(I, lam + dl, 0.0), lam)
 
     def jacobian_xu_batch(self, x, u):
         """The simulator's `Dq_nextDq | Dq_nextDqa_cmd` (irs_lqr/quasistatic_dynamics.py:184-191,
