@@ -18,9 +18,9 @@ underneath:
     quasistatic_simulator.  All four gradient modes run: "zero_order_B", "zero_order_AB" (the damped
     joint fit of calc_AB_zero_order), "first_order" (the mean over the u-perturbed samples of the
     step's active-set derivative -- the simulator's Dq_nextDqa_cmd -- computed per sample inside the
-    sample pass) and "exact" (that derivative at the nominal point).  The sample-pass modes return
-    the decoupled pair, so they need decouple_AB = True (every example of the reference sets it);
-    "exact" also runs with decouple_AB = False (full [Dq_nextDq | Dq_nextDqa_cmd]).
+    sample pass) and "exact" (that derivative at the nominal point).  The sample-pass kernels return
+    the decoupled pair (decouple_AB = True: every example of the reference); with decouple_AB = False
+    the full pair is assembled from the pass's statistics and the f64 Jacobian lanes (slower paths).
 
 `params.sampling(std_u_initial, iter)` returns the std of the u-perturbations like the reference;
 the draws are made on the host by `np.random.normal(0, std_u, (num_samples, dim_u))` once per
@@ -86,11 +86,6 @@ class IrsLqrQuasistatic(QuasistaticOptimizerBase):
             setattr(self, name, getattr(params, name))
         if self.gradient_mode not in ("zero_order_B", "zero_order_AB", "first_order", "exact"):
             raise RuntimeError(f"AB mode {self.gradient_mode} is not supported.")   # quasistatic_dynamics.py:238
-        if self.gradient_mode != "exact" and not self.decouple_AB:
-            raise NotImplementedError(
-                "gradient_mode=%r with decouple_AB=False: the device sample pass returns the decoupled "
-                "(A, B) of irs_lqr_quasistatic.py:275-284 (every example of the reference sets "
-                "decouple_AB=True); only \"exact\" keeps the full Jacobian" % (self.gradient_mode,))
         if self.x_bounds_rel is not None:
             raise NotImplementedError("x_bounds_rel ('should be rarely used', irs_lqr_quasistatic.py:315) "
                                       "is not implemented on the device")
@@ -115,6 +110,8 @@ class IrsLqrQuasistatic(QuasistaticOptimizerBase):
             return self._zero_order_AB_dev(x_trj, u_trj, std_u)
         if self.gradient_mode == "exact":
             return self._exact_dev(x_trj, u_trj)
+        if self.gradient_mode == "first_order" and not self.decouple_AB:
+            return self._first_order_full_dev(x_trj, u_trj, std_u)
         # "zero_order_B": least-squares fit of B; "first_order": mean of the per-sample derivative
         MODE = SMOOTH_FIRST_ORDER if self.gradient_mode == "first_order" else SMOOTH_ZERO_ORDER_B
         rank, world = dist_util.rank_world()
@@ -132,6 +129,8 @@ class IrsLqrQuasistatic(QuasistaticOptimizerBase):
                 o = self._dm.smooth_rng(MODE, x_trj, u_trj, N, None, std_u, int(seed),
                                         self.current_iter)
             self._smooth_info = o["info"]
+            if MODE == SMOOTH_ZERO_ORDER_B and not self.decouple_AB:
+                return self._zero_order_B_full_dev(x_trj, u_trj, o["sums"])
             return o["At"], o["Bt"], o["ct"]
         if seed is None:
             sums = self._dm.smooth_accumulate(MODE, x_trj, u_trj, None, du)
@@ -143,6 +142,60 @@ class IrsLqrQuasistatic(QuasistaticOptimizerBase):
         ws = self._dm._workspace(MODE, self.T, hi - lo, x_trj.device)
         At, Bt, ct, info = self._dm.smooth_finalize(MODE, N, x_trj, u_trj, sums, workspace=ws)
         self._smooth_info = info
+        if MODE == SMOOTH_ZERO_ORDER_B and not self.decouple_AB:
+            return self._zero_order_B_full_dev(x_trj, u_trj, sums)
+        return At, Bt, ct
+
+    # ---- decouple_AB = False: no example of the reference uses it; served from what the device already
+    #      offers (the statistics of the sample pass, the f64 active-set Jacobian), a few small launches more
+    def _zero_order_B_full_dev(self, x_trj, u_trj, sums):
+        """calc_B_zero_order without decouple_AB_matrices (quasistatic_dynamics.py:242-266): A = the step's
+        derivative at the nominal point, B = the least-squares fit, read off the (all-reduced) statistics
+        [upper Gram of du | du (f - xb)' | sum du] (include/irs_hip.h), xb = the f32-rounded nominal state."""
+        n, m, T = self.dim_x, self.dim_u, self.T
+        Ae, Be, ce = self._dm.exact_linearize(x_trj, u_trj)
+        x, u = x_trj[:-1], u_trj
+        f = ce + torch.einsum("tij,tj->ti", Ae, x) + torch.einsum("tij,tj->ti", Be, u)
+        iu = torch.triu_indices(m, m, device=sums.device)
+        ng = iu.shape[1]
+        G = torch.zeros((T, m, m), dtype=sums.dtype, device=sums.device)
+        G[:, iu[0], iu[1]] = sums[:, :ng]
+        G = G + torch.triu(G, 1).transpose(1, 2)
+        H = sums[:, ng:ng + m * n].reshape(T, m, n)
+        sz = sums[:, ng + m * n:ng + m * n + m]
+        xb = x.to(torch.float32).to(sums.dtype)
+        H = H - sz[:, :, None] * (f - xb)[:, None, :]
+        Bt = torch.linalg.solve(G, H).transpose(1, 2).contiguous()
+        ct = (f - torch.einsum("tij,tj->ti", Ae, x) - torch.einsum("tij,tj->ti", Bt, u)).contiguous()
+        return Ae, Bt, ct
+
+    def _first_order_full_dev(self, x_trj, u_trj, std_u):
+        """calc_AB_first_order without decouple_AB_matrices (quasistatic_dynamics.py:193-208): the mean over
+        the u-perturbed samples of the FULL [Dq_nextDq | Dq_nextDqa_cmd], from the f64 `jacobian_xu_batch`
+        lanes (one per sample), time step by time step; ranks own shards of the samples and all-reduce the
+        (T, n (n+m)) sums."""
+        rank, world = dist_util.rank_world()
+        N, n, m, T = self.num_samples, self.dim_x, self.dim_u, self.T
+        lo, hi = dist_util.shard_range(N, rank, world)
+        seed = getattr(self.params, "device_rng_seed", None)
+        if seed is None:
+            du = np.stack([np.random.normal(0, std_u, size=[N, m]) for _ in range(T)])
+            du = dev.to_dev(np.ascontiguousarray(du[:, lo:hi]))
+        else:
+            _, du32 = self._dm.rng_samples(T, hi - lo, np.zeros(n), std_u, int(seed), self.current_iter,
+                                           sample_offset=lo)
+            du = du32.to(dev.F64)
+        sums = torch.zeros((T, n * (n + m)), dtype=dev.F64, device=x_trj.device)
+        for t in range(T):
+            X = x_trj[t].expand(hi - lo, n).contiguous()
+            U = (u_trj[t] + du[t]).contiguous()
+            sums[t] = self._dm.jacobian_xu_batch(X, U).sum(0).reshape(-1)
+        dist_util.all_reduce_sums(sums)
+        AB = (sums / float(N)).reshape(T, n, n + m)
+        At, Bt = AB[:, :, :n].contiguous(), AB[:, :, n:].contiguous()
+        x_next = self._dm.dynamics_batch(x_trj[:-1].contiguous(), u_trj)
+        ct = (x_next - torch.einsum("tij,tj->ti", At, x_trj[:-1]) - torch.einsum("tij,tj->ti", Bt, u_trj)).contiguous()
+        self._smooth_info = torch.zeros(T, dtype=torch.int32, device=x_trj.device)
         return At, Bt, ct
 
     def _exact_dev(self, x_trj, u_trj):
@@ -193,6 +246,8 @@ class IrsLqrQuasistatic(QuasistaticOptimizerBase):
         ws = self._dm._workspace(SMOOTH_ZERO_ORDER_AB, T, hi - lo, x_trj.device)
         At, Bt, ct, info = self._dm.smooth_finalize(SMOOTH_ZERO_ORDER_AB, N, x_trj, u_trj, sums, workspace=ws)
         self._smooth_info = info
+        if not self.decouple_AB:
+            return At, Bt, ct
         # f = c + A x + B u with the fitted pair; then overwrite the structure and rebuild c
         f = ct + torch.einsum("tij,tj->ti", At, x_trj[:-1]) + torch.einsum("tij,tj->ti", Bt, u_trj)
         eye_m = torch.eye(m, dtype=At.dtype, device=At.device)

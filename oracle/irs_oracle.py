@@ -749,10 +749,11 @@ class BoxPushOracle(BoxPivotOracle):
         return [self.h, self.mass, self.inertia, self.half, self.mu, self.kp, self.r_hand, self.pgs_iters]
 
 
-def zero_order_B_decoupled(system, x_trj, u_trj, du):
-    """calc_B_zero_order (irs_lqr/quasistatic_dynamics.py:242-266, u-only noise) followed by
-    decouple_AB_matrices (irs_lqr/irs_lqr_quasistatic.py:275-284): A = I with the actuated columns
-    zeroed, the actuated rows of B = I; c = f - A x - B u (irs_lqr_quasistatic.py:313-316)."""
+def zero_order_B_decoupled(system, x_trj, u_trj, du, decouple=True):
+    """calc_B_zero_order (irs_lqr/quasistatic_dynamics.py:242-266, u-only noise: B by least squares, A =
+    the simulator's Dq_nextDq at the nominal point) followed -- `decouple` -- by decouple_AB_matrices
+    (irs_lqr/irs_lqr_quasistatic.py:275-284): A = I with the actuated columns zeroed, the actuated rows of
+    B = I; c = f - A x - B u (irs_lqr_quasistatic.py:313-316)."""
     T, n, m = u_trj.shape[0], system.dim_x, system.dim_u
     idx = system.indices_u_into_x
     At, Bt, ct = np.zeros((T, n, n)), np.zeros((T, n, m)), np.zeros((T, n))
@@ -760,9 +761,12 @@ def zero_order_B_decoupled(system, x_trj, u_trj, du):
         ft = system.dynamics(x_trj[t], u_trj[t])
         fdt = system.dynamics_batch(np.tile(x_trj[t], (du.shape[1], 1)), u_trj[t] + du[t])
         Bt[t] = zero_order_B_fit(du[t], fdt - ft)
-        Bt[t][idx, :] = np.eye(m)
-        At[t] = np.eye(n)
-        At[t][:, idx] = 0.0
+        if decouple:
+            Bt[t][idx, :] = np.eye(m)
+            At[t] = np.eye(n)
+            At[t][:, idx] = 0.0
+        else:
+            At[t] = system.jacobian_xu(x_trj[t], u_trj[t])[:, :n]
         ct[t] = ft - At[t].dot(x_trj[t]) - Bt[t].dot(u_trj[t])
     return At, Bt, ct
 
@@ -776,7 +780,7 @@ def _decouple(system, At, Bt):
     return At, Bt
 
 
-def first_order_B_decoupled(system, x_trj, u_trj, du):
+def first_order_B_decoupled(system, x_trj, u_trj, du, decouple=True):
     """gradient_mode "first_order": calc_AB_first_order (irs_lqr/quasistatic_dynamics.py:193-208, u-only
     noise, mean over the samples of the simulator's [Dq_nextDq | Dq_nextDqa_cmd]) followed by
     decouple_AB_matrices, which keeps only the unactuated rows of the mean B; c = f - A x - B u
@@ -786,7 +790,9 @@ def first_order_B_decoupled(system, x_trj, u_trj, du):
     for t in range(T):
         AB = system.jacobian_xu_batch(np.tile(x_trj[t], (du.shape[1], 1)), u_trj[t] + du[t])
         Bt[t] = AB[:, :, n:].mean(0)
-    At, Bt = _decouple(system, At, Bt)
+        At[t] = AB[:, :, :n].mean(0)
+    if decouple:
+        At, Bt = _decouple(system, At, Bt)
     for t in range(T):
         ft = system.dynamics(x_trj[t], u_trj[t])
         ct[t] = ft - At[t].dot(x_trj[t]) - Bt[t].dot(u_trj[t])
@@ -916,7 +922,7 @@ def zero_order_B_fit(du, dx_next):
     return np.linalg.lstsq(du, dx_next, rcond=None)[0].transpose()
 
 
-def zero_order_AB_damped_decoupled(system, x_trj, u_trj, dx, du, damp=1e-2):
+def zero_order_AB_damped_decoupled(system, x_trj, u_trj, dx, du, damp=1e-2, decouple=True):
     """calc_AB_zero_order (irs_lqr/quasistatic_dynamics.py:268-300): least squares of the one-step
     responses on [dx | du] with `damp`-weighted identity rows appended (Tikhonov), followed by
     decouple_AB_matrices (irs_lqr_quasistatic.py:275-284) and c = f - A x - B u."""
@@ -931,9 +937,12 @@ def zero_order_AB_damped_decoupled(system, x_trj, u_trj, dx, du, damp=1e-2):
         rhs = np.vstack([dfn, np.zeros((d, n))])
         AB = np.linalg.lstsq(lhs, rhs, rcond=None)[0].T
         Bt[t] = AB[:, n:]
-        Bt[t][idx, :] = np.eye(m)
-        At[t] = np.eye(n)
-        At[t][:, idx] = 0.0
+        if decouple:
+            Bt[t][idx, :] = np.eye(m)
+            At[t] = np.eye(n)
+            At[t][:, idx] = 0.0
+        else:
+            At[t] = AB[:, :n]
         ct[t] = ft - At[t].dot(x_trj[t]) - Bt[t].dot(u_trj[t])
     return At, Bt, ct
 

@@ -1290,13 +1290,59 @@ def test_irs_lqr_quasistatic_zero_order_AB_mode(amd):
     c0 = sol.cost
     sol.iterate(2)
     assert sol.cost_best < c0
-    # the sample-pass modes return the decoupled pair only
-    p.gradient_mode, p.decouple_AB = "first_order", False
-    with pytest.raises(NotImplementedError):
-        amd.IrsLqrQuasistatic(sys_d, p)
     p.gradient_mode = "nope"
     with pytest.raises(RuntimeError):
         amd.IrsLqrQuasistatic(sys_d, p)
+
+
+@pytest.mark.parametrize("mode", ["zero_order_B", "zero_order_AB", "first_order"])
+def test_quasistatic_gradient_modes_without_decoupling(amd, mode):
+    """decouple_AB = False (no example of the reference uses it): the full (A, B) of calc_B_zero_order
+    (A = the step's derivative at the nominal point), calc_AB_zero_order (damped joint fit) and
+    calc_AB_first_order (mean of the full sampled Jacobians) == the oracle on the reference's draws."""
+    T, N = 6, 1200
+    sys_d, sys_o, x0, u_trj, _, _, _, (Q, Qd, R, xd) = _hand_problem(amd, T, 4, 0)
+    p = amd.IrsLqrQuasistaticParameters()
+    q_dict = {"sphere": np.array([1e-3, 1e-3, 10.0]), "arm_left": np.array([1e-3, 1e-3]),
+              "arm_right": np.array([1e-3, 1e-3])}
+    p.Q_dict, p.Qd_dict = q_dict, {k: 100 * v for k, v in q_dict.items()}
+    p.R_dict = {"arm_left": 5 * np.ones(2), "arm_right": 5 * np.ones(2)}
+    p.x0, p.x_trj_d, p.u_trj_0, p.T = x0, xd, u_trj, T
+    p.u_bounds_abs = np.array([-np.ones(4) * 0.05, np.ones(4) * 0.05])
+    p.sampling = lambda u_initial, it: u_initial / (it ** 0.8)
+    p.std_u_initial, p.num_samples = np.ones(4) * 0.1, N
+    p.publish_every_iteration = False
+    p.gradient_mode, p.decouple_AB = mode, False
+    sol = amd.IrsLqrQuasistatic(sys_d, p)
+    sol.verbose = False
+    np.random.seed(9)
+    At, Bt, ct = sol.get_TV_matrices(sol.x_trj, sol.u_trj)
+    np.random.seed(9)
+    if mode == "zero_order_AB":
+        dx, du = [], []
+        for _ in range(T):
+            dx.append(np.random.normal(0, 1e-3, size=[N, 7]))
+            du.append(np.random.normal(0, p.std_u_initial, size=[N, 4]))
+        dx = np.stack(dx).astype(np.float32).astype(np.float64)
+        du = np.stack(du).astype(np.float32).astype(np.float64)
+        Ao, Bo, co = orc.zero_order_AB_damped_decoupled(sys_o, sol.x_trj, sol.u_trj, dx, du, decouple=False)
+        tolA, tolB = 2e-2, 5e-4           # A is fitted from 1e-3 state noise through f32 steps: ill-conditioned by design
+    else:
+        du = np.stack([np.random.normal(0, p.std_u_initial, size=[N, 4]) for _ in range(T)])
+        if mode == "zero_order_B":
+            du = du.astype(np.float32).astype(np.float64)
+            Ao, Bo, co = orc.zero_order_B_decoupled(sys_o, sol.x_trj, sol.u_trj, du, decouple=False)
+            tolA, tolB = 1e-8, 5e-4
+        else:
+            Ao, Bo, co = orc.first_order_B_decoupled(sys_o, sol.x_trj, sol.u_trj, du, decouple=False)
+            tolA, tolB = 1e-8, 1e-8      # f64 lanes on the f64 draws
+    np.testing.assert_allclose(At, Ao, rtol=0, atol=tolA)
+    np.testing.assert_allclose(Bt, Bo, rtol=0, atol=tolB)
+    np.testing.assert_allclose(ct, co, rtol=0, atol=max(tolA, tolB))
+    assert np.abs(At - np.eye(7)).max() > 1e-3                  # not the decoupled structure
+    c0 = sol.cost
+    sol.iterate(1)
+    assert np.isfinite(sol.cost_best) and sol.cost_best <= c0 * 1.5
 
 
 @pytest.mark.parametrize("mode", ["first_order", "exact"])
