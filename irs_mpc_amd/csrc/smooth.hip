@@ -770,9 +770,10 @@ void plan_grid(int T, int N, bool light, bool rng, int* chunk, int* nblk, int* b
     if (fill > by4) fill = by4;
     if (nb < fill) nb = fill;
     // heavy kernels: 1 workgroup per CU, 2 once there is enough work to hide the tail.  Contact
-    // kernels (one VALU-saturating wave per SIMD) switch later: at T = 50 two workgroups per CU lose
-    // 35 % at N = 4e4, 13 % at 6e4, and win 7 % from N = 1e5 on (measured, profiles/).
-    const long long two_per_cu = contact ? 5000000 : 2000000;
+    // kernels never: since the active-set polish they need more than 256 registers (VGPRs + AGPRs), one
+    // wave per SIMD is all a CU can hold, and a second workgroup per CU would only queue behind the first
+    // (before the polish, two per CU won 7 % from N = 1e5 on and lost below that: profiles/).
+    const long long two_per_cu = contact ? (1LL << 62) : 2000000;
     const int heavy_cap = tune_max_wg_heavy() * ((long long)N * T >= two_per_cu ? 2 : 1);
     int max_blk = (light ? tune_max_wg() : heavy_cap) / T;
     if (max_blk < 1) max_blk = 1;
