@@ -1,0 +1,1129 @@
+// Randomised-smoothing linearisation: get_TV_matrices of
+//   irs_lqr/irs_lqr_zero_order.py:38-63   (ZERO_ORDER_AB)
+//   irs_lqr/irs_lqr_first_order.py:28-54  (FIRST_ORDER)
+//   irs_lqr/quasistatic_dynamics.py:242-266 (ZERO_ORDER_B, u-only noise)
+//   irs_lqr/irs_lqr_exact.py:15-31        (exact)
+// as ONE launch: a streaming map-reduce over the (T x N) grid of independent one-step
+// samples whose last-arriving workgroup per timestep finishes the job.
+//
+//   smooth_kernel   grid (nblk, T) x 256 threads.
+//     1. every lane streams its samples' z=[dx|du] (f32, vector loads, consecutive
+//        lanes read consecutive records), evaluates the model functor in f32 and
+//        accumulates the P sufficient statistics of its timestep in registers;
+//     2. the workgroup transpose-reduces them with wave shuffles + one LDS hop and
+//        publishes its P partial sums (write-through stores), then takes a ticket on
+//        the timestep's arrival counter;
+//     3. the workgroup that draws the last ticket of timestep t re-reads the nblk
+//        partials in a FIXED order (f64) -> sums[t][P]   (deterministic: no float
+//        atomics, the arrival order never changes the summation order);
+//     4. (single-GPU path) its first wave solves the Jacobi-scaled normal equations
+//        by Cholesky in f64 -> A_t, B_t and c_t = f(x_t,u_t) - A_t x_t - B_t u_t.
+//   With several GPUs step 4 is a separate launch (smooth_finalize_kernel) after the
+//   all-reduce of `sums`.
+//
+// Inter-workgroup hand-off follows cdna_hip_programming.md Guideline 16: partials are
+// stored sc1 (agent-scope relaxed atomic stores), every storing wave drains vmcnt, the
+// workgroup barriers, one lane adds to the counter; the consumer does one agent-scope
+// acquire + vmcnt(0) + barrier before any load of the partials.
+#include <cstdlib>
+#include "irs_common.hpp"
+#include "philox.hpp"
+#include "reduce.hpp"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+constexpr int kCounterBytes = 4096;   // head of the workspace: arrival counters
+// then T rows of f64 nominal steps (n <= 32)
+constexpr size_t fnom_bytes(int T) { return (size_t)T * 32 * sizeof(double); }
+
+// models whose step is expensive and has no Jacobian (contact QPs): in the fused launch workgroup
+// 0 of every timestep takes fewer samples and evaluates the f64 nominal step the solve needs while
+// the other workgroups are still sampling, instead of the last arriver doing it serially
+template <class Model, int MODE>
+constexpr bool nominal_in_wg0() { return !Model::HAS_JACOBIAN; }
+constexpr int kNominalCost = 3;      // the f64 nominal step costs about this many f32 sample evaluations
+
+template <class Model, int MODE>
+struct SmoothTraits {
+    static constexpr int n = Model::NX, m = Model::NU, d = n + m;
+    // perturbed components that enter the least-squares design matrix
+    static constexpr int NZ = (MODE == IRS_SMOOTH_ZERO_ORDER_B) ? m : d;
+    // first perturbed component: n when only u is perturbed (ZERO_ORDER_B; FIRST_ORDER of a contact model)
+    static constexpr int Z0 = (MODE == IRS_SMOOTH_ZERO_ORDER_B || (MODE == IRS_SMOOTH_FIRST_ORDER && !Model::HAS_JACOBIAN)) ? n : 0;
+    static constexpr int NG = NZ * (NZ + 1) / 2;
+    // zero-order statistics: upper Gram of z and z df'.  Models with an expensive step (contact QPs)
+    // take df = f(x+dx,u+du) - xb and append sum(z): the solve then subtracts the nominal step,
+    // (sum z)(f(x,u) - xb)', so that no lane of the sample pass has to evaluate f(x,u) (one whole
+    // sample evaluation per lane otherwise).  Cheap analytic steps keep df = f(..) - f(x,u): for them
+    // the three extra accumulators cost more than the nominal evaluation (measured, pendulum).
+    static constexpr bool SUMZ = MODE != IRS_SMOOTH_FIRST_ORDER && !Model::HAS_JACOBIAN;
+    static constexpr int NH = NG + NZ * n;     // offset of the sum-of-z block
+    // first-order statistics: the sum of the sampled Jacobians [A | B] (n x d).  Contact models perturb
+    // u only (calc_AB_first_order, quasistatic_dynamics.py:193-208) and return the decoupled pair like
+    // ZERO_ORDER_B, so only the n x m block B of the active-set derivative is summed
+    static constexpr bool FIRST_B = MODE == IRS_SMOOTH_FIRST_ORDER && !Model::HAS_JACOBIAN;
+    static constexpr int P = FIRST_B ? n * m
+                             : (MODE == IRS_SMOOTH_FIRST_ORDER) ? n * d : NG + NZ * n + (SUMZ ? NZ : 0);
+    static constexpr int PP = irs_reduce_pad(P);
+    // last-arriver reduction: NGRP groups of P lanes each sum a strided subset of blocks
+    static constexpr int NGRP = (P >= kBlock) ? 1 : kBlock / P;
+    // light = few accumulators AND a small functor: fits 1024-thread workgroups (128 VGPRs)
+    static constexpr bool LIGHT = PP <= 32 && d <= 7 && Model::HAS_JACOBIAN;   // contact steps are never light
+};
+
+struct SmoothArgs {
+    ModelParams p;
+    const double* x_trj;
+    const double* u_trj;
+    const float* dx;
+    const float* du;
+    float std[32];
+    unsigned long long seed;
+    unsigned long long sample_offset;
+    unsigned int iter;
+    int T, N, chunk, nblk, block;
+    int diag;          // tuning experiments only (IRS_DIAG): 1 = skip the fused solve
+    int* counters;     // (T) arrival counters, zero between calls
+    float* partial;    // (T, nblk, P)
+    double* fnom;      // (T, n) f64 nominal steps written by workgroup 0 when chunk0 < chunk
+    int chunk0;        // samples of workgroup 0 (== chunk unless it also evaluates the nominal step)
+    double* sums;      // (T, P) out
+    // finalize outputs (fused path only)
+    double* At;
+    double* Bt;
+    double* ct;
+    int* info;
+    double n_total;
+};
+
+template <int K>
+__device__ __forceinline__ void load_row(const float* __restrict__ ptr, float* out) {
+    if constexpr (K % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < K / 4; ++i) {
+            float4 v = reinterpret_cast<const float4*>(ptr)[i];
+            out[4 * i] = v.x; out[4 * i + 1] = v.y; out[4 * i + 2] = v.z; out[4 * i + 3] = v.w;
+        }
+    } else if constexpr (K % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < K / 2; ++i) {
+            float2 v = reinterpret_cast<const float2*>(ptr)[i];
+            out[2 * i] = v.x; out[2 * i + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < K; ++i) out[i] = ptr[i];
+    }
+}
+
+// Orders this wave's LDS traffic (the LDS executes one wave's operations in issue
+// order; this only stops the compiler from moving them) -- a barrier for ONE wave.
+__device__ __forceinline__ void wave_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// 1/sqrt(x) to ~1 ulp: hardware estimate + three Newton steps.  A correctly rounded f64
+// sqrt followed by a divide is ~70 dependent instructions on the critical path of EVERY
+// elimination step of the in-kernel solve.
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const double h = 0.5 * x * y;
+        y = fma(fma(-h, y, 0.5), y, y);
+    }
+    return y;
+}
+
+template <class Model, int MODE>
+struct FinalizeLds {
+    using TR = SmoothTraits<Model, MODE>;
+    double G[TR::NZ][TR::NZ + 1];
+    double H[TR::NZ][TR::n];
+    double sc[TR::NZ];
+    double fd[TR::n];            // f(x_t,u_t) - (the f32-rounded) x_t
+    double AB[TR::n][TR::d];
+    int bad;
+};
+
+// Solve step for timestep t, executed by ONE wave (lane = 0..63).  S: the P f64 sums of
+// the timestep (LDS or global).
+template <class Model, int MODE>
+__device__ __forceinline__ void finalize_timestep(const ModelParams& p, const double* x_trj,
+                                                  const double* u_trj, const double* S, double n_total,
+                                                  int t, int lane, FinalizeLds<Model, MODE>& L,
+                                                  double* At, double* Bt, double* ct, int* info,
+                                                  const double* fnom = nullptr) {
+    using TR = SmoothTraits<Model, MODE>;
+    constexpr int n = TR::n, m = TR::m, d = TR::d, NZ = TR::NZ, Z0 = TR::Z0;
+    // f(x_t, u_t) in f64: evaluated here, or -- for models whose step is expensive (contact QPs) --
+    // already evaluated by workgroup 0 of the fused launch, which takes fewer samples in exchange
+    auto nominal = [&](const double* x, const double* u, double* f) {
+        if (fnom != nullptr) {
+#pragma unroll
+            for (int i = 0; i < n; ++i) f[i] = fnom[i];
+        } else {
+            Model::template step<double>(p, x, u, f);
+        }
+    };
+
+    double x[n], u[m], f[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) x[i] = x_trj[(size_t)t * n + i];
+#pragma unroll
+    for (int j = 0; j < m; ++j) u[j] = u_trj[(size_t)t * m + j];
+
+    if (lane == 0) L.bad = 0;
+    if constexpr (TR::FIRST_B) {
+        // mean of the sampled B, inside the decoupled structure (irs_lqr_quasistatic.py:275-284)
+        nominal(x, u, f);
+        for (int q = lane; q < n * n; q += 64) {
+            int i = q / n, k = q % n;
+            bool act = false;
+            for (int j = 0; j < m; ++j) act = act || (Model::u_into_x(j) == k);
+            L.AB[i][k] = (i == k && !act) ? 1.0 : 0.0;
+        }
+        for (int q = lane; q < n * m; q += 64) L.AB[q / m][n + q % m] = S[q] / n_total;
+    } else if constexpr (MODE == IRS_SMOOTH_FIRST_ORDER) {
+        Model::template step<double>(p, x, u, f);
+        for (int q = lane; q < n * d; q += 64) L.AB[q / d][q % d] = S[q] / n_total;
+    } else {
+        if constexpr (MODE == IRS_SMOOTH_ZERO_ORDER_B) {
+            if constexpr (Model::HAS_JACOBIAN) {
+                // A = exact Jacobian at the nominal point (quasistatic_dynamics.py:254-256)
+                double J[n * d];
+                model_jacobian<Model, double>(p, x, u, f, J);
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < n; ++i)
+#pragma unroll
+                        for (int k = 0; k < n; ++k) L.AB[i][k] = J[i * d + k];
+                }
+            } else {
+                // decouple_AB (irs_lqr_quasistatic.py:275-284): A = I with the actuated
+                // columns zeroed (the actuated rows of B become I after the fit, below)
+                nominal(x, u, f);
+                for (int q = lane; q < n * n; q += 64) {
+                    int i = q / n, k = q % n;
+                    bool act = false;
+                    for (int j = 0; j < m; ++j) act = act || (Model::u_into_x(j) == k);
+                    L.AB[i][k] = (i == k && !act) ? 1.0 : 0.0;
+                }
+            }
+        } else {
+            nominal(x, u, f);
+        }
+        if constexpr (NZ <= 4) {
+            // tiny system: every lane solves it in registers (no LDS round trips)
+            double g[NZ][NZ], h[NZ][n], scl[NZ], lo[NZ][NZ];
+            int badr = 0;
+#pragma unroll
+            for (int i = 0; i < NZ; ++i)
+#pragma unroll
+                for (int j = i; j < NZ; ++j) {
+                    g[i][j] = S[i * NZ - i * (i - 1) / 2 + (j - i)];
+                    g[j][i] = g[i][j];
+                }
+            // H = sum z (f(x+dx,u+du) - f(x,u))' = sum z (f(..) - xb)' - (sum z)(f(x,u) - xb)', xb = the
+            // f32-rounded nominal state the sample pass subtracted
+#pragma unroll
+            for (int i = 0; i < NZ; ++i)
+#pragma unroll
+                for (int k = 0; k < n; ++k) {
+                    h[i][k] = S[TR::NG + i * n + k];
+                    if constexpr (TR::SUMZ) h[i][k] -= S[TR::NH + i] * (f[k] - (double)(float)x[k]);
+                }
+#pragma unroll
+            for (int i = 0; i < NZ; ++i) {
+                bool pos = g[i][i] > 0.0;
+                scl[i] = pos ? fast_rsqrt(g[i][i]) : 0.0;
+                if (!pos && badr == 0) badr = i + 1;
+            }
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) {
+                double djj = g[j][j] * scl[j] * scl[j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) djj -= lo[j][k] * lo[j][k];
+                if (!(djj > 1e-14)) {
+                    if (badr == 0) badr = j + 1;
+                    djj = 1.0;
+                }
+                const double il = fast_rsqrt(djj);
+                lo[j][j] = il;                       // the diagonal keeps 1/l_jj
+#pragma unroll
+                for (int i = j + 1; i < NZ; ++i) {
+                    double s = g[i][j] * scl[i] * scl[j];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) s -= lo[i][k] * lo[j][k];
+                    lo[i][j] = s * il;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < n; ++k) {
+                double y[NZ];
+#pragma unroll
+                for (int i = 0; i < NZ; ++i) {
+                    double s = h[i][k] * scl[i];
+#pragma unroll
+                    for (int l = 0; l < i; ++l) s -= lo[i][l] * y[l];
+                    y[i] = s * lo[i][i];
+                }
+#pragma unroll
+                for (int i = NZ - 1; i >= 0; --i) {
+                    double s = y[i];
+#pragma unroll
+                    for (int l = i + 1; l < NZ; ++l) s -= lo[l][i] * y[l];
+                    y[i] = s * lo[i][i];
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < NZ; ++i) L.AB[k][Z0 + i] = y[i] * scl[i];
+                }
+            }
+            if (lane == 0 && badr != 0) L.bad = badr;
+        } else {
+        // unpack the upper-triangular Gram and the cross term
+        for (int q = lane; q < NZ * NZ; q += 64) {
+            int i = q / NZ, j = q % NZ;
+            int r = i < j ? i : j, c = i < j ? j : i;
+            L.G[i][j] = S[r * NZ - r * (r - 1) / 2 + (c - r)];
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < n; ++k) L.fd[k] = f[k] - (double)(float)x[k];
+        }
+        wave_sync();
+        for (int q = lane; q < NZ * n; q += 64) {
+            double hq = S[TR::NG + q];
+            if constexpr (TR::SUMZ) hq -= S[TR::NH + q / n] * L.fd[q % n];
+            L.H[q / n][q % n] = hq;
+        }
+        wave_sync();
+        // Jacobi scaling: G' = D G D, H' = D H, D = diag(G)^-1/2
+        if (lane < NZ) {
+            double g = L.G[lane][lane];
+            L.sc[lane] = g > 0.0 ? 1.0 / sqrt(g) : 0.0;
+            if (!(g > 0.0)) L.bad = lane + 1;
+        }
+        wave_sync();
+        for (int q = lane; q < NZ * NZ; q += 64) L.G[q / NZ][q % NZ] *= L.sc[q / NZ] * L.sc[q % NZ];
+        for (int q = lane; q < NZ * n; q += 64) L.H[q / n][q % n] *= L.sc[q / n];
+        wave_sync();
+        // Right-looking Cholesky of G' with the forward substitution folded in: the
+        // right-hand sides H' ride along as extra columns (after step j row j of H' holds
+        // y_j and the rows below have had L[r][j] y_j removed), then a column-oriented
+        // back substitution.  Every update is spread over the 64 lanes; nothing is
+        // unrolled (unrolling the solves hoists NZ^2/2 factor loads into registers and
+        // would cap the whole fused sample kernel at one wave per SIMD).
+        static_assert(NZ <= 32 && n <= 32, "lane split of the scaling step");
+        for (int j = 0; j < NZ; ++j) {
+            double djj = L.G[j][j];
+            if (!(djj > 1e-14)) {
+                if (lane == 0 && L.bad == 0) L.bad = j + 1;
+                djj = 1.0;
+            }
+            const double il = fast_rsqrt(djj);
+            wave_sync();
+            if (lane == j) L.G[j][j] = il;                            // the diagonal keeps 1/l_jj
+            if (lane > j && lane < NZ) L.G[lane][j] *= il;            // L[r][j]
+            if (lane >= 32 && lane < 32 + n) L.H[j][lane - 32] *= il; // y_j
+            wave_sync();
+            for (int q = lane; q < NZ * NZ; q += 64) {                // (r,c), j < c <= r
+                int r = q / NZ, c = q % NZ;
+                if (c > j && r >= c) L.G[r][c] -= L.G[r][j] * L.G[c][j];
+            }
+            for (int q = lane; q < NZ * n; q += 64) {                 // rows below j of H'
+                int r = q / n, k = q % n;
+                if (r > j) L.H[r][k] -= L.G[r][j] * L.H[j][k];
+            }
+            wave_sync();
+        }
+        // L' w = y, column oriented
+        for (int i = NZ - 1; i >= 0; --i) {
+            const double il = L.G[i][i];
+            wave_sync();
+            if (lane < n) L.H[i][lane] *= il;                         // w_i
+            wave_sync();
+            for (int q = lane; q < i * n; q += 64) {
+                int r = q / n, k = q % n;
+                L.H[r][k] -= L.G[i][r] * L.H[i][k];
+            }
+        }
+        wave_sync();
+        for (int q = lane; q < NZ * n; q += 64) L.AB[q % n][Z0 + q / n] = L.H[q / n][q % n] * L.sc[q / n];
+        }  // NZ > 4
+    }
+    wave_sync();
+    if constexpr ((MODE == IRS_SMOOTH_ZERO_ORDER_B && !Model::HAS_JACOBIAN) || TR::FIRST_B) {
+        for (int q = lane; q < m * m; q += 64) L.AB[Model::u_into_x(q / m)][n + q % m] = (q / m == q % m) ? 1.0 : 0.0;
+        wave_sync();
+    }
+    for (int q = lane; q < n * n; q += 64) At[(size_t)t * n * n + q] = L.AB[q / n][q % n];
+    for (int q = lane; q < n * m; q += 64) Bt[(size_t)t * n * m + q] = L.AB[q / m][n + q % m];
+    if (lane < n) {
+        double c = f[0];
+#pragma unroll
+        for (int i = 0; i < n; ++i) c = (i == lane) ? f[i] : c;
+#pragma unroll
+        for (int i = 0; i < n; ++i) c -= L.AB[lane][i] * x[i];
+#pragma unroll
+        for (int j = 0; j < m; ++j) c -= L.AB[lane][n + j] * u[j];
+        ct[(size_t)t * n + lane] = c;
+    }
+    if (lane == 0) info[t] = L.bad;
+}
+
+template <class Model, int MODE, bool RNG, bool FUSE, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
+    using TR = SmoothTraits<Model, MODE>;
+    constexpr int n = TR::n, m = TR::m, d = TR::d, NZ = TR::NZ, Z0 = TR::Z0, P = TR::P;
+    constexpr int NW = BLOCK / 64;
+    constexpr int P4 = (P + 3) / 4 * 4;     // row stride of the partial buffer (16-byte rows)
+    // matrix-core Gram path: zero-order, one 16-wide tile, too many statistics for registers
+    constexpr bool USE_MFMA = MODE == IRS_SMOOTH_ZERO_ORDER_AB && d <= 16 && n <= 16 && TR::PP > 64 &&
+                              BLOCK == kBlock;
+    __shared__ float red[NW * TR::PP];
+    __shared__ float tile[USE_MFMA ? NW * 64 * 36 : 1];
+    __shared__ double red64[TR::NGRP * P];
+    __shared__ double tot[P];
+    __shared__ FinalizeLds<Model, MODE> fin;
+    __shared__ int s_ticket;
+
+    const int t = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+
+    // nominal point of this timestep (every lane keeps its own copy in registers)
+    float xb[n], ub[m], f0[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) xb[i] = (float)a.x_trj[(size_t)t * n + i];
+#pragma unroll
+    for (int j = 0; j < m; ++j) ub[j] = (float)a.u_trj[(size_t)t * m + j];
+    // what the samples' f(x+dx,u+du) is measured from: the nominal step, or (TR::SUMZ) just xb
+    if constexpr (MODE != IRS_SMOOTH_FIRST_ORDER && !TR::SUMZ) Model::template step<float>(a.p, xb, ub, f0);
+    else {
+#pragma unroll
+        for (int i = 0; i < n; ++i) f0[i] = xb[i];
+    }
+
+    // workgroup 0 owns [0, chunk0), workgroup b >= 1 owns chunk0 + [(b-1) chunk, b chunk)
+    const int s_begin = blk == 0 ? 0 : a.chunk0 + (blk - 1) * a.chunk;
+    const int s_end = min(a.N, blk == 0 ? a.chunk0 : a.chunk0 + blk * a.chunk);
+    constexpr bool NB = false;
+    if constexpr (USE_MFMA) {
+        // ---- matrix-core Gram accumulation (zero-order, d <= 16, many statistics) -------
+        // The P = d(d+1)/2 + d n statistics are the products Z'Z and Z'dF over the sample
+        // axis: exactly what v_mfma_f32_16x16x4_f32 contracts (k = 4 samples per issue),
+        // with the accumulators in 8 registers per WAVE instead of P per LANE.  Each lane
+        // evaluates one sample, stages [z | df] as a row of its wave's LDS tile (row stride
+        // 36 dwords: conflict-free 16-byte writes), and the wave re-reads the tile in
+        // operand layout (lane (i = l&15, k = l>>4) <- row 4 kk + k, column i); Z serves as
+        // both the A and the B operand of Z'Z.  f32 MFMA is an exact k-ordered fmaf chain.
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        constexpr int TS = 36;
+        const int lane = tid & 63, wave = tid >> 6, col = lane & 15, rg = lane >> 4;
+        float* my = tile + wave * 64 * TS;
+        v4f aG = {0.f, 0.f, 0.f, 0.f}, aH = {0.f, 0.f, 0.f, 0.f};
+        for (int s0 = s_begin + wave * 64; s0 < s_end; s0 += BLOCK) {
+            const int s = s0 + lane;
+            const bool valid = s < s_end;
+            float z[16], dfp[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { z[i] = 0.f; dfp[i] = 0.f; }
+            if constexpr (RNG) {
+                const unsigned long long gidx = a.sample_offset + (unsigned long long)s;
+#pragma unroll
+                for (int j = 0; j < (d + 3) / 4; ++j) {
+                    float g[4];
+                    philox_normal4(gidx, (unsigned)t, (unsigned)j, a.iter, a.seed, g);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (4 * j + c < d) z[4 * j + c] = g[c] * a.std[4 * j + c];
+                }
+            } else {
+                const size_t row = (size_t)t * a.N + (valid ? s : s_end - 1);
+                load_row<n>(a.dx + row * n, z);
+                load_row<m>(a.du + row * m, z + n);
+            }
+#pragma unroll
+            for (int i = 0; i < d; ++i) z[i] = valid ? z[i] : 0.f;
+            float xs[n], us[m], fx[n];
+#pragma unroll
+            for (int i = 0; i < n; ++i) xs[i] = xb[i] + z[i];
+#pragma unroll
+            for (int j = 0; j < m; ++j) us[j] = ub[j] + z[n + j];
+            Model::template step<float>(a.p, xs, us, fx);
+#pragma unroll
+            for (int k = 0; k < n; ++k) dfp[k] = fx[k] - f0[k];      // (!SUMZ: 0 for a zeroed slot)
+            if constexpr (TR::SUMZ) {
+                static_assert(!TR::SUMZ || n < 16, "column n of the dF tile carries the ones that sum z");
+                dfp[n < 16 ? n : 0] = 1.f;                           // z of an invalid slot is 0
+            }
+            float4* rowp = reinterpret_cast<float4*>(my + lane * TS);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                rowp[q] = make_float4(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]);
+                rowp[4 + q] = make_float4(dfp[4 * q], dfp[4 * q + 1], dfp[4 * q + 2], dfp[4 * q + 3]);
+            }
+            wave_sync();
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const float av = my[(4 * kk + rg) * TS + col];
+                const float bv = my[(4 * kk + rg) * TS + 16 + col];
+                aG = __builtin_amdgcn_mfma_f32_16x16x4f32(av, av, aG, 0, 0, 0);
+                aH = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, aH, 0, 0, 0);
+            }
+            wave_sync();
+        }
+        // accumulator (row = 4 (l>>4) + reg, col = l&15) -> this wave's row of `red`, P-order
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * rg + r, j = col;
+            if (i < d && j < d && i <= j) red[wave * TR::PP + i * d - i * (i - 1) / 2 + (j - i)] = aG[r];
+            if (i < d && j < n) red[wave * TR::PP + TR::NG + i * n + j] = aH[r];
+            if constexpr (TR::SUMZ) {
+                if (i < d && j == n) red[wave * TR::PP + TR::NH + i] = aH[r];
+            }
+        }
+    } else {
+        float acc[TR::PP];
+#pragma unroll
+        for (int i = 0; i < TR::PP; ++i) acc[i] = 0.f;
+
+        // Sample loop.  U samples per lane are loaded together (independent loads in
+        // flight), then evaluated; out-of-range slots are clamped to a valid address and
+        // zeroed (a zero perturbation contributes exactly nothing to the zero-order sums).
+        constexpr int U = (TR::LIGHT && !RNG) ? 4 : 1;
+        for (int s0 = s_begin + tid; s0 < s_end; s0 += BLOCK * U) {
+            float zz[U][d];
+            bool valid[U];
+#pragma unroll
+            for (int uu = 0; uu < U; ++uu) {
+                const int s = s0 + uu * BLOCK;
+                valid[uu] = s < s_end;
+                if constexpr (RNG) {
+                    constexpr int j0 = Z0 / 4;
+                    const unsigned long long gidx = a.sample_offset + (unsigned long long)s;
+#pragma unroll
+                    for (int j = j0; j < (d + 3) / 4; ++j) {
+                        float g[4];
+                        philox_normal4(gidx, (unsigned)t, (unsigned)j, a.iter, a.seed, g);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (4 * j + c < d) zz[uu][4 * j + c] = g[c] * a.std[4 * j + c];
+                    }
+#pragma unroll
+                    for (int i = 0; i < Z0; ++i) zz[uu][i] = 0.f;
+                } else {
+                    const size_t row = (size_t)t * a.N + (valid[uu] ? s : s_end - 1);
+                    if constexpr (Z0 == 0) load_row<n>(a.dx + row * n, zz[uu]);
+                    else {
+#pragma unroll
+                        for (int i = 0; i < n; ++i) zz[uu][i] = 0.f;
+                    }
+                    load_row<m>(a.du + row * m, zz[uu] + n);
+                }
+            }
+#pragma unroll
+            for (int uu = 0; uu < U; ++uu) {
+                float z[d];
+#pragma unroll
+                for (int i = 0; i < d; ++i) z[i] = (U == 1 || valid[uu]) ? zz[uu][i] : 0.f;
+                float xs[n], us[m], fx[n];
+#pragma unroll
+                for (int i = 0; i < n; ++i) xs[i] = xb[i] + z[i];
+#pragma unroll
+                for (int j = 0; j < m; ++j) us[j] = ub[j] + z[n + j];
+
+                if constexpr (TR::FIRST_B) {
+                    float Bs[n * m];
+                    irs_contact_step_grad<Model, float, false>(a.p, xs, us, fx, Bs, nullptr);
+#pragma unroll
+                    for (int q = 0; q < n * m; ++q) acc[q] += Bs[q];
+                } else if constexpr (MODE == IRS_SMOOTH_FIRST_ORDER) {
+                    float J[n * d];
+                    model_jacobian<Model, float>(a.p, xs, us, fx, J);
+                    const float w = (U == 1 || valid[uu]) ? 1.f : 0.f;
+#pragma unroll
+                    for (int q = 0; q < n * d; ++q) acc[q] = fmaf(w, J[q], acc[q]);
+                } else {
+                    Model::template step<float>(a.p, xs, us, fx);
+                    float df[n];
+#pragma unroll
+                    for (int k = 0; k < n; ++k) df[k] = fx[k] - f0[k];
+                    int q = 0;
+#pragma unroll
+                    for (int i = 0; i < NZ; ++i)
+#pragma unroll
+                        for (int j = i; j < NZ; ++j) { acc[q] = fmaf(z[Z0 + i], z[Z0 + j], acc[q]); ++q; }
+#pragma unroll
+                    for (int i = 0; i < NZ; ++i)
+#pragma unroll
+                        for (int k = 0; k < n; ++k) { acc[q] = fmaf(z[Z0 + i], df[k], acc[q]); ++q; }
+                    if constexpr (TR::SUMZ) {
+#pragma unroll
+                        for (int i = 0; i < NZ; ++i) { acc[q] += z[Z0 + i]; ++q; }
+                    }
+                }
+            }
+        }
+
+        // ---- workgroup reduction: registers -> shuffles -> LDS ---------------------
+        block_reduce_lds<P, NW>(acc, red);
+    }
+    if constexpr (NB) {
+        // (a lone fused workgroup lets its solve evaluate the step itself: same cost, no round trip)
+        if (blk == 0 && (a.nblk > 1 || !FUSE) && tid < 64) {
+            double x64[n], u64[m], f64[n];
+#pragma unroll
+            for (int i = 0; i < n; ++i) x64[i] = a.x_trj[(size_t)t * n + i];
+#pragma unroll
+            for (int j = 0; j < m; ++j) u64[j] = a.u_trj[(size_t)t * m + j];
+            Model::template step<double>(a.p, x64, u64, f64);
+            if (tid == 0) {
+#pragma unroll
+                for (int i = 0; i < n; ++i)
+                    __hip_atomic_store(a.fnom + (size_t)t * n + i, f64[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    __syncthreads();
+
+    const int nblk = a.nblk;
+    if (nblk == 1) {
+        // the only workgroup of this timestep: totals straight from LDS
+        for (int q = tid; q < P; q += BLOCK) {
+            float s = red[q];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) s += red[w * TR::PP + q];
+            tot[q] = (double)s;
+        }
+    } else if constexpr (BLOCK == kBlock) {
+        // publish this workgroup's partial sums: 16-byte write-through (sc1) stores, one
+        // row of P4 floats per workgroup (few wide fabric writes instead of P narrow ones)
+        for (int q = tid; q < P; q += BLOCK) {
+            float s = red[q];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) s += red[w * TR::PP + q];
+            red[q] = s;                       // column q is touched by this lane only
+        }
+        __syncthreads();
+        {
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const unsigned bytes = (unsigned)((size_t)a.T * nblk * P4 * sizeof(float));
+            __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.partial, 0, bytes, 0x00020000);
+            const unsigned row = (unsigned)(((size_t)t * nblk + blk) * P4 * sizeof(float));
+            for (int q4 = tid; q4 < P4 / 4; q4 += BLOCK) {
+                u32x4 v;
+                v.x = __float_as_uint(red[4 * q4]);
+                v.y = __float_as_uint(red[4 * q4 + 1]);
+                v.z = __float_as_uint(red[4 * q4 + 2]);
+                v.w = __float_as_uint(red[4 * q4 + 3]);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, row + 16u * q4, 0, 16 /* sc1 */);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+            s_ticket = __hip_atomic_fetch_add(a.counters + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_ticket != nblk - 1) return;       // uniform over the workgroup
+        // ---- last arriver of timestep t ------------------------------------------
+        if (tid == 0) {
+            __hip_atomic_store(a.counters + t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const float* src = a.partial + (size_t)t * nblk * P4;
+        if constexpr (P >= kBlock) {
+            // plain loads are valid behind the acquire above; unrolled so that the
+            // (independent) loads are in flight together, summed in a fixed order
+            for (int q = tid; q < P; q += BLOCK) {
+                double s = 0.0;
+#pragma unroll 8
+                for (int b = 0; b < nblk; ++b) s += (double)src[(size_t)b * P4 + q];
+                tot[q] = s;
+            }
+        } else {
+            const int g = tid / P, q = tid % P;
+            if (g < TR::NGRP) {
+                double s = 0.0;
+#pragma unroll 4
+                for (int b = g; b < nblk; b += TR::NGRP) s += (double)src[(size_t)b * P4 + q];
+                red64[g * P + q] = s;
+            }
+            __syncthreads();
+            if (tid < P) {
+                double s = red64[tid];
+                for (int gg = 1; gg < TR::NGRP; ++gg) s += red64[gg * P + tid];
+                tot[tid] = s;
+            }
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < P; q += BLOCK) a.sums[(size_t)t * P + q] = tot[q];
+    if constexpr (FUSE) {
+        if (tid < 64 && a.diag != 1)
+            finalize_timestep<Model, MODE>(a.p, a.x_trj, a.u_trj, tot, a.n_total, t, tid, fin, a.At, a.Bt,
+                                           a.ct, a.info,
+                                           (NB && a.nblk > 1) ? a.fnom + (size_t)t * n : nullptr);
+    }
+}
+
+// Stand-alone solve (after an all-reduce of `sums`): one wave per timestep.
+template <class Model, int MODE>
+__global__ __launch_bounds__(64) void smooth_finalize_kernel(SmoothArgs a) {
+    __shared__ FinalizeLds<Model, MODE> fin;
+    const int t = blockIdx.x;
+    // a.fnom (optional): the f64 nominal steps a preceding irs_smooth_accumulate left in its workspace
+    const double* fnom = (nominal_in_wg0<Model, MODE>() && a.fnom) ? a.fnom + (size_t)t * SmoothTraits<Model, MODE>::n
+                                                                    : nullptr;
+    finalize_timestep<Model, MODE>(a.p, a.x_trj, a.u_trj, a.sums + (size_t)t * SmoothTraits<Model, MODE>::P,
+                                   a.n_total, t, threadIdx.x, fin, a.At, a.Bt, a.ct, a.info, fnom);
+}
+
+template <class Model>
+__global__ __launch_bounds__(64) void exact_linearize_kernel(ModelParams p, const double* x_trj,
+                                                             const double* u_trj, double* At, double* Bt,
+                                                             double* ct, int T) {
+    constexpr int n = Model::NX, m = Model::NU, d = n + m;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    double x[n], u[m], f[n], J[n * d];
+#pragma unroll
+    for (int i = 0; i < n; ++i) x[i] = x_trj[(size_t)t * n + i];
+#pragma unroll
+    for (int j = 0; j < m; ++j) u[j] = u_trj[(size_t)t * m + j];
+    model_jacobian<Model, double>(p, x, u, f, J);
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+        double c = f[i];
+#pragma unroll
+        for (int k = 0; k < n; ++k) {
+            At[((size_t)t * n + i) * n + k] = J[i * d + k];
+            c -= J[i * d + k] * x[k];
+        }
+#pragma unroll
+        for (int k = 0; k < m; ++k) {
+            Bt[((size_t)t * n + i) * m + k] = J[i * d + n + k];
+            c -= J[i * d + n + k] * u[k];
+        }
+        ct[(size_t)t * n + i] = c;
+    }
+}
+
+template <int n, int m>
+__global__ void rng_samples_kernel(float* dx, float* du, SmoothArgs a) {
+    constexpr int d = n + m;
+    const int t = blockIdx.y;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.N) return;
+    const unsigned long long gidx = a.sample_offset + (unsigned long long)s;
+    float z[(d + 3) / 4 * 4];
+#pragma unroll
+    for (int j = 0; j < (d + 3) / 4; ++j) philox_normal4(gidx, (unsigned)t, (unsigned)j, a.iter, a.seed, z + 4 * j);
+    const size_t row = (size_t)t * a.N + s;
+#pragma unroll
+    for (int i = 0; i < n; ++i) dx[row * n + i] = z[i] * a.std[i];
+#pragma unroll
+    for (int j = 0; j < m; ++j) du[row * m + j] = z[n + j] * a.std[n + j];
+}
+
+// Planner knobs (environment overrides are for tuning experiments only).
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    int v = e ? atoi(e) : dflt;
+    return v < 1 ? 1 : v;
+}
+int tune_spt() { static int v = env_int("IRS_SPT", 32); return v; }                 // samples per lane aimed for
+int tune_single_max() { static int v = env_int("IRS_SINGLE_MAX", 16384); return v; } // <= : one WG per t
+int tune_max_wg() { static int v = env_int("IRS_MAX_WG", 1024); return v; }         // grid cap, light kernels
+int tune_max_wg_heavy() { static int v = env_int("IRS_MAX_WG_HEAVY", 256); return v; }  // 1 wave/SIMD kernels
+int tune_min_wg() { static int v = env_int("IRS_MIN_WG", 256); return v; }          // fill the CUs
+
+constexpr int kBigBlock = 1024;
+
+// Chooses the launch geometry for (T, N).  `light` = the kernel's accumulators fit a
+// 1024-thread workgroup (SmoothTraits::LIGHT).  Measured on MI355X (profiles/): every extra
+// workgroup costs more (its hand-off: write-through stores + ticket) than it gains in
+// streaming parallelism once the CUs are covered, so grids stay SMALL:
+//  * light, samples supplied, N <= tune_single_max(): ONE 1024-thread workgroup per
+//    timestep -- no inter-workgroup hand-off at all;
+//  * otherwise 256-thread workgroups, ~tune_spt() samples per lane, at least enough
+//    workgroups to cover the CUs (while each lane still has >= 4 samples) and at most
+//    ~4 per CU (light kernels) or 1 per CU (kernels that hold 1 wave per SIMD).
+void plan_grid(int T, int N, bool light, bool rng, int* chunk, int* nblk, int* block, bool contact = false) {
+    if (light && !rng && N <= tune_single_max()) {
+        *block = kBigBlock;
+        *nblk = 1;
+        *chunk = (N + kBigBlock - 1) / kBigBlock * kBigBlock;
+        return;
+    }
+    *block = kBlock;
+    if (T < 1) T = 1;
+    const int spt = tune_spt();
+    int nb = (N + kBlock * spt - 1) / (kBlock * spt);
+    int fill = (tune_min_wg() + T - 1) / T;               // blocks per t that cover the CUs
+    int by4 = (N + kBlock * 4 - 1) / (kBlock * 4);        // ... keeping >= 4 samples per lane
+    if (fill > by4) fill = by4;
+    if (nb < fill) nb = fill;
+    // heavy kernels: 1 workgroup per CU, 2 once there is enough work to hide the tail.  Contact
+    // kernels never: since the active-set polish they need more than 256 registers (VGPRs + AGPRs), one
+    // wave per SIMD is all a CU can hold, and a second workgroup per CU would only queue behind the first
+    // (before the polish, two per CU won 7 % from N = 1e5 on and lost below that: profiles/).
+    const long long two_per_cu = contact ? (1LL << 62) : 2000000;
+    const int heavy_cap = tune_max_wg_heavy() * ((long long)N * T >= two_per_cu ? 2 : 1);
+    int max_blk = (light ? tune_max_wg() : heavy_cap) / T;
+    if (max_blk < 1) max_blk = 1;
+    if (nb > max_blk) nb = max_blk;
+    if (nb < 1) nb = 1;
+    int c = (N + nb - 1) / nb;
+    c = (c + kBlock - 1) / kBlock * kBlock;
+    *chunk = c;
+    *nblk = (N + c - 1) / c;
+    if (*nblk < 1) *nblk = 1;
+}
+
+template <class Model, int MODE>
+int sums_len_t() { return SmoothTraits<Model, MODE>::P; }
+
+template <class Model>
+bool light_m(int mode) {
+    switch (mode) {
+        case IRS_SMOOTH_ZERO_ORDER_AB: return SmoothTraits<Model, IRS_SMOOTH_ZERO_ORDER_AB>::LIGHT;
+        case IRS_SMOOTH_FIRST_ORDER: return SmoothTraits<Model, IRS_SMOOTH_FIRST_ORDER>::LIGHT;
+        case IRS_SMOOTH_ZERO_ORDER_B: return SmoothTraits<Model, IRS_SMOOTH_ZERO_ORDER_B>::LIGHT;
+    }
+    return false;
+}
+
+bool is_light(int model, int mode) {
+    switch (model) {
+        case IRS_MODEL_PENDULUM: return light_m<PendulumModel>(mode);
+        case IRS_MODEL_QUADROTOR: return light_m<QuadrotorModel>(mode);
+        case IRS_MODEL_BICYCLE: return light_m<BicycleModel>(mode);
+        case IRS_MODEL_THREE_CART: return light_m<ThreeCartModel>(mode);
+        case IRS_MODEL_PLANAR_HAND: return light_m<PlanarHandModel>(mode);
+        case IRS_MODEL_BOX_PIVOT: return light_m<BoxPivotModel>(mode);
+        case IRS_MODEL_BOX_ON_BOX: return light_m<BoxOnBoxModel>(mode);
+        case IRS_MODEL_BOX_PUSH: return light_m<BoxPushModel>(mode);
+        case IRS_MODEL_PLANAR_HAND_EXACT: return light_m<PlanarHandExactModel>(mode);
+    }
+    return false;
+}
+
+bool has_nominal_in_wg0(int model, int mode) {
+    bool r = false;
+    (void)mode;
+    IRS_DISPATCH_MODEL(model, { r = !Model::HAS_JACOBIAN; });
+    return r;
+}
+
+template <class Model>
+int sums_len_m(int mode) {
+    switch (mode) {
+        case IRS_SMOOTH_ZERO_ORDER_AB: return sums_len_t<Model, IRS_SMOOTH_ZERO_ORDER_AB>();
+        case IRS_SMOOTH_FIRST_ORDER: return sums_len_t<Model, IRS_SMOOTH_FIRST_ORDER>();
+        case IRS_SMOOTH_ZERO_ORDER_B: return sums_len_t<Model, IRS_SMOOTH_ZERO_ORDER_B>();
+    }
+    return -1;
+}
+
+template <class Model, int MODE, int BLOCK>
+void launch_smooth_b(const SmoothArgs& a, bool rng, bool fuse, hipStream_t st) {
+    dim3 grid(a.nblk, a.T), block(BLOCK);
+    if (rng) {
+        if (fuse) hipLaunchKernelGGL((smooth_kernel<Model, MODE, true, true, BLOCK>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((smooth_kernel<Model, MODE, true, false, BLOCK>), grid, block, 0, st, a);
+    } else {
+        if (fuse) hipLaunchKernelGGL((smooth_kernel<Model, MODE, false, true, BLOCK>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((smooth_kernel<Model, MODE, false, false, BLOCK>), grid, block, 0, st, a);
+    }
+}
+
+template <class Model, int MODE>
+void launch_smooth_m(const SmoothArgs& a, bool rng, bool fuse, hipStream_t st) {
+    if constexpr (SmoothTraits<Model, MODE>::LIGHT) {
+        if (a.block == kBigBlock) { launch_smooth_b<Model, MODE, kBigBlock>(a, rng, fuse, st); return; }
+    }
+    launch_smooth_b<Model, MODE, kBlock>(a, rng, fuse, st);
+}
+
+template <class Model>
+int launch_smooth(int mode, const SmoothArgs& a, bool rng, bool fuse, hipStream_t st) {
+    switch (mode) {
+        case IRS_SMOOTH_ZERO_ORDER_AB: launch_smooth_m<Model, IRS_SMOOTH_ZERO_ORDER_AB>(a, rng, fuse, st); break;
+        case IRS_SMOOTH_FIRST_ORDER: launch_smooth_m<Model, IRS_SMOOTH_FIRST_ORDER>(a, rng, fuse, st); break;
+        case IRS_SMOOTH_ZERO_ORDER_B: launch_smooth_m<Model, IRS_SMOOTH_ZERO_ORDER_B>(a, rng, fuse, st); break;
+        default: return IRS_ERR_UNSUPPORTED;
+    }
+    return IRS_OK;
+}
+
+template <class Model>
+int launch_finalize(int mode, const SmoothArgs& a, hipStream_t st) {
+    dim3 grid(a.T), block(64);
+    switch (mode) {
+        case IRS_SMOOTH_ZERO_ORDER_AB:
+            hipLaunchKernelGGL((smooth_finalize_kernel<Model, IRS_SMOOTH_ZERO_ORDER_AB>), grid, block, 0, st, a);
+            break;
+        case IRS_SMOOTH_FIRST_ORDER:
+            hipLaunchKernelGGL((smooth_finalize_kernel<Model, IRS_SMOOTH_FIRST_ORDER>), grid, block, 0, st, a);
+            break;
+        case IRS_SMOOTH_ZERO_ORDER_B:
+            hipLaunchKernelGGL((smooth_finalize_kernel<Model, IRS_SMOOTH_ZERO_ORDER_B>), grid, block, 0, st, a);
+            break;
+        default: return IRS_ERR_UNSUPPORTED;
+    }
+    return IRS_OK;
+}
+
+struct SmoothOut {   // finalize outputs; all null = accumulate only
+    double* At; double* Bt; double* ct; int* info; long long n_total;
+};
+
+int smooth_common(int model, const double* params, int n_params, int mode, int T, int N,
+                  const double* x_trj, const double* u_trj, SmoothArgs& a, bool rng, double* sums,
+                  const SmoothOut* out, void* workspace, size_t workspace_bytes, void* stream) {
+    IRS_CHECK_ARG(T > 0 && N > 0, "T and N must be positive");
+    IRS_CHECK_ARG(x_trj && u_trj && sums && workspace, "null pointer");
+    IRS_CHECK_ARG(mode >= 0 && mode <= 2, "unknown smoothing mode");
+    IRS_CHECK_ARG((size_t)T * sizeof(int) <= kCounterBytes, "T too large for the arrival counters (max 1024)");
+    int rc = irs_load_params(model, params, n_params, &a.p);
+    if (rc != IRS_OK) return rc;
+    size_t need = irs_smooth_workspace_bytes(model, mode, T, N);
+    if (workspace_bytes < need) {
+        irs_set_error("irs_smooth: workspace %zu < %zu bytes", workspace_bytes, need);
+        return IRS_ERR_WORKSPACE;
+    }
+    a.x_trj = x_trj; a.u_trj = u_trj;
+    a.T = T; a.N = N;
+    plan_grid(T, N, is_light(model, mode), rng, &a.chunk, &a.nblk, &a.block, has_nominal_in_wg0(model, mode));
+    a.chunk0 = a.chunk;
+    if (a.nblk >= 2 && a.block == kBlock && has_nominal_in_wg0(model, mode)) {
+        // workgroup 0 gives up kNominalCost samples per lane and evaluates the f64 nominal step
+        int c0 = a.chunk - kNominalCost * kBlock;
+        if (c0 < kBlock) c0 = kBlock;
+        int rest = (N - c0 + (a.nblk - 1) - 1) / (a.nblk - 1);
+        rest = (rest + kBlock - 1) / kBlock * kBlock;
+        if (c0 < a.chunk && c0 + (long long)(a.nblk - 1) * rest >= N && rest <= a.chunk + kBlock) {
+            a.chunk0 = c0;
+            a.chunk = rest;
+        }
+    }
+    { static int dg = getenv("IRS_DIAG") ? atoi(getenv("IRS_DIAG")) : 0; a.diag = dg; }
+    a.counters = static_cast<int*>(workspace);
+    a.fnom = reinterpret_cast<double*>(static_cast<char*>(workspace) + kCounterBytes);
+    a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + kCounterBytes + fnom_bytes(T));
+    a.sums = sums;
+    const bool fuse = out != nullptr;
+    if (fuse) {
+        IRS_CHECK_ARG(out->At && out->Bt && out->ct && out->info && out->n_total > 0, "null output pointer");
+        a.At = out->At; a.Bt = out->Bt; a.ct = out->ct; a.info = out->info;
+        a.n_total = (double)out->n_total;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    IRS_DISPATCH_MODEL(model, { rc = launch_smooth<Model>(mode, a, rng, fuse, st); });
+    if (rc != IRS_OK) return rc;
+    IRS_CHECK_LAUNCH();
+    return IRS_OK;
+}
+
+// modes that perturb u only never read dx / std_x
+bool u_noise_only(int model, int mode) {
+    if (mode == IRS_SMOOTH_ZERO_ORDER_B) return true;
+    bool contact = false;
+    IRS_DISPATCH_MODEL(model, { contact = !Model::HAS_JACOBIAN; });
+    return contact && mode == IRS_SMOOTH_FIRST_ORDER;
+}
+
+int fill_rng(int model, int mode, const double* std_x, const double* std_u, uint64_t seed, uint32_t iter,
+             uint64_t sample_offset, SmoothArgs& a) {
+    IRS_CHECK_ARG(std_u != nullptr, "std_u is null");
+    IRS_CHECK_ARG(std_x != nullptr || u_noise_only(model, mode), "std_x is null");
+    int n, m, np;
+    int rc = irs_model_info(model, &n, &m, &np);
+    if (rc != IRS_OK) return rc;
+    for (int i = 0; i < n; ++i) a.std[i] = std_x ? (float)std_x[i] : 0.f;
+    for (int j = 0; j < m; ++j) a.std[n + j] = (float)std_u[j];
+    a.seed = seed; a.iter = iter; a.sample_offset = sample_offset;
+    return IRS_OK;
+}
+
+int check_samples(const float* dx, const float* du, int model, int mode) {
+    IRS_CHECK_ARG(du != nullptr, "du is null");
+    IRS_CHECK_ARG(dx != nullptr || u_noise_only(model, mode), "dx is null");
+    IRS_CHECK_ARG((reinterpret_cast<uintptr_t>(dx) & 15) == 0 && (reinterpret_cast<uintptr_t>(du) & 15) == 0,
+                  "dx/du must be 16-byte aligned");
+    return IRS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int irs_sums_len(int model, int mode) {
+    if (mode < 0 || mode > 2) { irs_set_error("irs_sums_len: unknown mode %d", mode); return IRS_ERR_INVALID_ARG; }
+    IRS_DISPATCH_MODEL(model, { return sums_len_m<Model>(mode); });
+    return IRS_ERR_UNSUPPORTED;
+}
+
+size_t irs_smooth_workspace_bytes(int model, int mode, int T, int N) {
+    int P = irs_sums_len(model, mode);
+    if (P <= 0 || T <= 0 || N <= 0) return 0;
+    int chunk, nblk, block;
+    plan_grid(T, N, is_light(model, mode), /*rng=*/true, &chunk, &nblk, &block,       // the larger grid
+              has_nominal_in_wg0(model, mode));
+    return kCounterBytes + fnom_bytes(T) + (size_t)T * nblk * ((P + 3) / 4 * 4) * sizeof(float);
+}
+
+int irs_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
+    IRS_CHECK_ARG(workspace != nullptr && workspace_bytes >= (size_t)kCounterBytes, "workspace too small");
+    hipError_t e = hipMemsetAsync(workspace, 0, kCounterBytes, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) { irs_set_error("irs_workspace_init: %s", hipGetErrorString(e)); return IRS_ERR_HIP; }
+    return IRS_OK;
+}
+
+int irs_smooth_accumulate(int model, const double* params, int n_params, int mode, int T, int N,
+                          const double* x_trj, const double* u_trj, const float* dx,
+                          const float* du, double* sums, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+    int rc = check_samples(dx, du, model, mode);
+    if (rc != IRS_OK) return rc;
+    SmoothArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dx = dx; a.du = du;
+    return smooth_common(model, params, n_params, mode, T, N, x_trj, u_trj, a, false, sums, nullptr,
+                         workspace, workspace_bytes, stream);
+}
+
+int irs_smooth_accumulate_rng(int model, const double* params, int n_params, int mode, int T, int N,
+                              const double* x_trj, const double* u_trj, const double* std_x,
+                              const double* std_u, uint64_t seed, uint32_t iter,
+                              uint64_t sample_offset, double* sums, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    SmoothArgs a;
+    memset(&a, 0, sizeof(a));
+    int rc = fill_rng(model, mode, std_x, std_u, seed, iter, sample_offset, a);
+    if (rc != IRS_OK) return rc;
+    return smooth_common(model, params, n_params, mode, T, N, x_trj, u_trj, a, true, sums, nullptr,
+                         workspace, workspace_bytes, stream);
+}
+
+int irs_smooth(int model, const double* params, int n_params, int mode, int T, int N,
+               const double* x_trj, const double* u_trj, const float* dx, const float* du,
+               double* sums, double* At, double* Bt, double* ct, int* info, void* workspace,
+               size_t workspace_bytes, void* stream) {
+    int rc = check_samples(dx, du, model, mode);
+    if (rc != IRS_OK) return rc;
+    SmoothArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dx = dx; a.du = du;
+    SmoothOut out{At, Bt, ct, info, (long long)N};
+    return smooth_common(model, params, n_params, mode, T, N, x_trj, u_trj, a, false, sums, &out,
+                         workspace, workspace_bytes, stream);
+}
+
+int irs_smooth_rng(int model, const double* params, int n_params, int mode, int T, int N,
+                   const double* x_trj, const double* u_trj, const double* std_x, const double* std_u,
+                   uint64_t seed, uint32_t iter, double* sums, double* At, double* Bt, double* ct,
+                   int* info, void* workspace, size_t workspace_bytes, void* stream) {
+    SmoothArgs a;
+    memset(&a, 0, sizeof(a));
+    int rc = fill_rng(model, mode, std_x, std_u, seed, iter, 0, a);
+    if (rc != IRS_OK) return rc;
+    SmoothOut out{At, Bt, ct, info, (long long)N};
+    return smooth_common(model, params, n_params, mode, T, N, x_trj, u_trj, a, true, sums, &out,
+                         workspace, workspace_bytes, stream);
+}
+
+int irs_smooth_run(const irs_smooth_call* c, void* stream) {
+    IRS_CHECK_ARG(c != nullptr, "null call struct");
+    SmoothArgs a;
+    memset(&a, 0, sizeof(a));
+    int rc;
+    if (c->use_rng) {
+        rc = fill_rng(c->model, c->mode, c->std_x, c->std_u, c->seed, c->iter, c->sample_offset, a);
+    } else {
+        rc = check_samples(c->dx, c->du, c->model, c->mode);
+        a.dx = c->dx; a.du = c->du;
+    }
+    if (rc != IRS_OK) return rc;
+    SmoothOut out{c->At, c->Bt, c->ct, c->info, c->n_total};
+    return smooth_common(c->model, c->params, c->n_params, c->mode, c->T, c->N, c->x_trj, c->u_trj, a,
+                         c->use_rng != 0, c->sums, c->At ? &out : nullptr, c->workspace,
+                         c->workspace_bytes, stream);
+}
+
+int irs_rng_samples(int n, int m, int T, int N, const double* std_x, const double* std_u,
+                    uint64_t seed, uint32_t iter, uint64_t sample_offset, float* dx, float* du,
+                    void* stream) {
+    IRS_CHECK_ARG(T > 0 && N > 0 && dx && du && std_x && std_u, "bad argument");
+    SmoothArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int i = 0; i < n; ++i) a.std[i] = (float)std_x[i];
+    for (int j = 0; j < m; ++j) a.std[n + j] = (float)std_u[j];
+    a.seed = seed; a.iter = iter; a.sample_offset = sample_offset; a.T = T; a.N = N;
+    dim3 grid((N + 255) / 256, T), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (n == 2 && m == 1) hipLaunchKernelGGL((rng_samples_kernel<2, 1>), grid, block, 0, st, dx, du, a);
+    else if (n == 12 && m == 4) hipLaunchKernelGGL((rng_samples_kernel<12, 4>), grid, block, 0, st, dx, du, a);
+    else if (n == 5 && m == 2) hipLaunchKernelGGL((rng_samples_kernel<5, 2>), grid, block, 0, st, dx, du, a);
+    else if (n == 6 && m == 2) hipLaunchKernelGGL((rng_samples_kernel<6, 2>), grid, block, 0, st, dx, du, a);
+    else if (n == 7 && m == 4) hipLaunchKernelGGL((rng_samples_kernel<7, 4>), grid, block, 0, st, dx, du, a);
+    else { irs_set_error("irs_rng_samples: unsupported (n,m)=(%d,%d)", n, m); return IRS_ERR_UNSUPPORTED; }
+    IRS_CHECK_LAUNCH();
+    return IRS_OK;
+}
+
+int irs_smooth_finalize(int model, const double* params, int n_params, int mode, int T,
+                        long long N_total, const double* x_trj, const double* u_trj,
+                        const double* sums, double* At, double* Bt, double* ct, int* info,
+                        void* stream) {
+    return irs_smooth_finalize_ws(model, params, n_params, mode, T, N_total, x_trj, u_trj, sums, At, Bt, ct, info,
+                                  nullptr, 0, stream);
+}
+
+int irs_smooth_finalize_ws(int model, const double* params, int n_params, int mode, int T,
+                           long long N_total, const double* x_trj, const double* u_trj,
+                           const double* sums, double* At, double* Bt, double* ct, int* info,
+                           const void* workspace, size_t workspace_bytes, void* stream) {
+    IRS_CHECK_ARG(T > 0 && N_total > 0, "T and N_total must be positive");
+    IRS_CHECK_ARG(workspace == nullptr || workspace_bytes >= (size_t)kCounterBytes + fnom_bytes(T),
+                  "workspace too small to hold the nominal steps");
+    IRS_CHECK_ARG(x_trj && u_trj && sums && At && Bt && ct && info, "null pointer");
+    IRS_CHECK_ARG(mode >= 0 && mode <= 2, "unknown smoothing mode");
+    SmoothArgs a;
+    memset(&a, 0, sizeof(a));
+    int rc = irs_load_params(model, params, n_params, &a.p);
+    if (rc != IRS_OK) return rc;
+    a.x_trj = x_trj; a.u_trj = u_trj; a.sums = const_cast<double*>(sums);
+    a.At = At; a.Bt = Bt; a.ct = ct; a.info = info;
+    a.n_total = (double)N_total; a.T = T;
+    if (workspace != nullptr)
+        a.fnom = reinterpret_cast<double*>(static_cast<char*>(const_cast<void*>(workspace)) + kCounterBytes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    IRS_DISPATCH_MODEL(model, { rc = launch_finalize<Model>(mode, a, st); });
+    if (rc != IRS_OK) return rc;
+    IRS_CHECK_LAUNCH();
+    return IRS_OK;
+}
+
+int irs_exact_linearize(int model, const double* params, int n_params, int T, const double* x_trj,
+                        const double* u_trj, double* At, double* Bt, double* ct, void* stream) {
+    IRS_CHECK_ARG(T > 0 && x_trj && u_trj && At && Bt && ct, "bad argument");
+    ModelParams p;
+    int rc = irs_load_params(model, params, n_params, &p);
+    if (rc != IRS_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    IRS_DISPATCH_MODEL(model, {
+        hipLaunchKernelGGL((exact_linearize_kernel<Model>), dim3((T + 63) / 64), dim3(64), 0, st, p,
+                           x_trj, u_trj, At, Bt, ct, T);
+    });
+    IRS_CHECK_LAUNCH();
+    return IRS_OK;
+}
+
+}  // extern "C"
