@@ -814,9 +814,9 @@ bool is_light(int model, int mode) {
     return false;
 }
 
-bool has_nominal_in_wg0(int model, int mode) {
+// contact models, in every smoothing mode (nominal_in_wg0<Model, MODE>)
+bool has_nominal_in_wg0(int model, int /*mode*/) {
     bool r = false;
-    (void)mode;
     IRS_DISPATCH_MODEL(model, { r = !Model::HAS_JACOBIAN; });
     return r;
 }

@@ -299,8 +299,9 @@ class _ContactQPOracle:
         return self.dynamics_batch(x[None], u[None])[0]
 
     def dynamics_exact(self, x, u):
-        """The same QP solved to optimality (L-BFGS-B on the dual): the physics check of the
-        fixed-sweep PGS."""
+        """The same QP solved to optimality by an independent method (L-BFGS-B on the dual): the physics
+        check of the sweeps.  It stalls on a few degenerate samples (rank-deficient W with many active rows);
+        `_dual_exact` (pgs_iters = 0) is the exact solver, certified through the QP's KKT conditions."""
         from scipy.optimize import minimize
         Dinv, b, J, phi = self._qp(x, u)
         b, J, phi = b[0], J[0], phi[0]
