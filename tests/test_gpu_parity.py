@@ -844,6 +844,45 @@ def test_planar_hand_exact_contact_solver_vs_oracle(amd):
         amd.PlanarHandDynamics(0.1, contact_solver="nope")
 
 
+def test_capture_step_replays_the_two_launch_smoothing_step(amd):
+    """irs_mpc_amd.distributed.capture_step (what bench.py times with several GPUs): the accumulate and
+    solve launches of the sharded smoothing step captured into one HIP graph; replays reproduce the eagerly
+    issued step bit for bit, also after the inputs changed in place."""
+    from irs_mpc_amd import device as dev
+    from irs_mpc_amd._lib import SMOOTH_ZERO_ORDER_B
+    from irs_mpc_amd.distributed import capture_step
+    T, N = 5, 700
+    sys_d, sys_o, x0, u_trj = _hand_setup(amd, T)
+    dm = sys_d.dm()
+    xd, ud = dev.to_dev(orc.rollout(sys_o, x0, u_trj)), dev.to_dev(u_trj)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    du = 0.1 * torch.randn((T, N, 4), generator=g, device="cuda", dtype=torch.float32)
+    plan = dev.SmoothPlan(dm, SMOOTH_ZERO_ORDER_B, xd, ud, du=du, fuse=False, n_total=N)
+    out = {}
+
+    def step():
+        plan.run()
+        out["o"] = dm.smooth_finalize(SMOOTH_ZERO_ORDER_B, N, xd, ud, plan.sums, out=out.get("o"), workspace=plan.ws)
+
+    step()
+    torch.cuda.synchronize()
+    ref = [t.clone() for t in out["o"][:3]]
+    replay = capture_step(step)
+    for t in out["o"][:3]:
+        t.zero_()
+    replay()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(ref, out["o"][:3]))
+    du.mul_(0.5)                                    # same buffers, new content: the graph reads them afresh
+    replay()
+    torch.cuda.synchronize()
+    got = [t.clone() for t in out["o"][:3]]
+    step()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(got, out["o"][:3]))
+    assert not torch.equal(got[1], ref[1])
+
+
 def test_planar_hand_descent_runs(amd):
     """smooth -> Riccati -> closed-loop rollout through the contact functor in f64 == oracle."""
     from irs_mpc_amd import device as dev
