@@ -1090,6 +1090,7 @@ def test_cem_quasistatic_vs_oracle(amd):
                                    "zero_order_B"],
                                   ["planar_hand", "irs_lqr", "--iters", "2", "--T", "12", "--N", "300", "--gradient-mode",
                                    "exact"],
+                                  ["planar_hand_spin", "irs_lqr", "--iters", "3", "--T", "20", "--N", "500"],
                                   ["planar_hand", "cem", "--iters", "3", "--T", "12", "--N", "60"],
                                   ["box_pivoting", "irs_lqr", "--iters", "3", "--T", "40", "--N", "500"],
                                   ["box_pivoting", "cem", "--iters", "3", "--T", "40", "--N", "80"],
