@@ -844,6 +844,29 @@ def test_planar_hand_exact_contact_solver_vs_oracle(amd):
         amd.PlanarHandDynamics(0.1, contact_solver="nope")
 
 
+def test_planar_hand_exact_solver_random_states(amd):
+    """The device's exact dual active-set solve on 4000 random states and commands -- separated, touching,
+    deeply penetrating, up to 7 rows active -- == the oracle's (which is KKT-certified on the same kind of
+    states, tests/test_oracle_golden.py); the active-set Jacobian too."""
+    rng = np.random.default_rng(321)
+    N = 4000
+    obj = np.stack([rng.uniform(-0.3, 0.3, N), rng.uniform(0.1, 0.7, N), rng.uniform(-1, 1, N)], 1)
+    left = np.stack([rng.uniform(-2.2, -0.2, N), rng.uniform(-1.5, 0.5, N)], 1)
+    right = np.stack([rng.uniform(0.2, 2.2, N), rng.uniform(-0.5, 1.5, N)], 1)
+    X = np.zeros((N, 7))
+    X[:, HAND.PERM] = np.hstack([obj, left, right])
+    U = X[:, HAND_IDX] + rng.normal(0, 0.3, (N, 4))
+    sys_o = orc.PlanarHandOracle(0.1, pgs_iters=0)
+    sys_d = amd.PlanarHandDynamics(0.1, contact_solver="exact")
+    want = sys_o.dynamics_batch(X, U)
+    got = sys_d.dynamics_batch(X, U)
+    assert np.isfinite(got).all()
+    step = np.abs(want - X).max(1, keepdims=True).clip(1e-3)
+    assert (np.abs(got - want) <= 1e-7 * step + 1e-9).all()
+    Jd, Jo = sys_d.jacobian_xu_batch(X[:500], U[:500]), sys_o.jacobian_xu_batch(X[:500], U[:500])
+    assert np.abs(Jd - Jo).max() < 1e-5
+
+
 def test_capture_step_replays_the_two_launch_smoothing_step(amd):
     """irs_mpc_amd.distributed.capture_step (what bench.py times with several GPUs): the accumulate and
     solve launches of the sharded smoothing step captured into one HIP graph; replays reproduce the eagerly
