@@ -42,6 +42,7 @@ IRS_HD S irs_max0(const S& a) { return irs_value(a) > 0 ? a : S(a * (typename sc
 // the exactly solved QP drops from 1e-2 (omega = 1) to 7e-4 (1.5), of 100 sweeps from 2e-3 to 1e-6; at
 // std 0.3 the 90th percentile drops 10-40x.  Free: the factor is folded into 1 / W_ii.
 constexpr double kContactPgsOmega = 1.5;
+constexpr int kContactExactWarmSweeps = 32;    // projected sweeps that guess the active set of the exact solve
 
 // 1/x: the hardware estimate (1 ulp) for f32 lanes, a true divide otherwise -- the dual active-set loop divides
 // 2 NC times per step, and a correctly rounded f32 divide is ~10 instructions
@@ -204,7 +205,8 @@ IRS_HD void irs_contact_qp_dual(const typename scalar_of<S>::type* Dinv, const S
 // blocking row are one-hot vectors, the factorisation of W_AA is the masked LDL' of irs_contact_qp_grad --
 // and the loop is wave-uniform: it ends when every lane of the wave is done (cap 4 NC steps; a lane that
 // hits the cap keeps its last multipliers, which are dual feasible).  Restated in oracle/irs_oracle.py
-// (_ContactQPOracle._dual_exact).  T = float or double.
+// (_ContactQPOracle._dual_exact, which starts every sample from lam = 0: the primal solution is unique, so
+// the warm start below changes the path, not the answer).  T = float or double.
 template <typename T>
 IRS_HD bool irs_wave_all(bool v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -251,6 +253,87 @@ IRS_HD void irs_contact_qp_dual_exact(const T* Dinv, const T* b, const T (*J)[NX
 #pragma unroll
     for (int i = 0; i < NC; ++i) scale = fmax(scale, fabs(g[i]));
     const T tolv = tol_rel * scale;
+    // ---- warm start.  The method may start from ANY pair (A, lam) with lam_A = -W_AA^-1 r_A >= 0 (the
+    // optimum of the QP restricted to A, multipliers of the right sign); a few over-relaxed projected sweeps
+    // guess A, and rows whose restricted multiplier comes out negative are released until the pair is
+    // valid.  From there the loop below typically needs 0-3 steps instead of 8-13 from lam = 0, and a wave
+    // runs as long as its slowest lane.  A lane whose guess cannot be repaired starts from lam = 0.
+    {
+        T r[NC], invw[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) { r[i] = g[i]; invw[i] = T(kContactPgsOmega) * irs_rcp_fast(Wd[i]); }
+        for (int sw = 0; sw < kContactExactWarmSweeps; ++sw) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                const T nw = fmax(lam[i] - g[i] * invw[i], T(0));
+                const T dl = nw - lam[i];
+                lam[i] = nw;
+#pragma unroll
+                for (int j = 0; j < NC; ++j) g[j] = g[j] + W[j][i] * dl;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NC; ++i) act[i] = lam[i] > T(0);
+        bool valid = false;
+        for (int round = 0; round < 3; ++round) {
+            if (irs_wave_all<T>(valid)) break;
+            T M_[NC][NC], inv[NC], y[NC];
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) M_[i][j] = W[i][j];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const T dj = M_[j][j];
+                const bool ok = act[j] && dj > piv_rel * Wd[j];
+                if (!valid) act[j] = ok;                              // a dependent row leaves the guess
+                inv[j] = ok ? irs_rcp_fast(dj) : T(0);
+#pragma unroll
+                for (int i = j + 1; i < NC; ++i) M_[j][i] = M_[i][j] * inv[j];
+#pragma unroll
+                for (int i = j + 1; i < NC; ++i)
+#pragma unroll
+                    for (int k = j + 1; k <= i; ++k) M_[i][k] = M_[i][k] - M_[j][i] * M_[k][j];
+            }
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                T v = act[j] ? -r[j] : T(0);
+#pragma unroll
+                for (int k = 0; k < j; ++k) v = v - M_[k][j] * y[k];
+                y[j] = v;
+            }
+#pragma unroll
+            for (int j = NC - 1; j >= 0; --j) {
+                T v = y[j] * inv[j];
+#pragma unroll
+                for (int i = j + 1; i < NC; ++i) v = v - M_[j][i] * y[i];
+                y[j] = v;
+            }
+            if (!valid) {
+                bool all_pos = true;
+#pragma unroll
+                for (int i = 0; i < NC; ++i) {
+                    const bool neg = act[i] && !(y[i] > T(0));
+                    all_pos = all_pos && !neg;
+                    lam[i] = act[i] ? y[i] : T(0);
+                    if (neg) act[i] = false;
+                }
+                valid = all_pos;
+            }
+        }
+        // slacks of the pair; an unrepaired guess falls back to the cold start
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            if (!valid) { lam[i] = T(0); act[i] = false; }
+        }
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            T s = r[i];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) s = s + W[i][j] * lam[j];
+            g[i] = act[i] ? T(0) : s;
+        }
+    }
     int p = -1;                    // candidate row, -1 = none
     bool done = false;
     for (int it = 0; it < 4 * NC; ++it) {

@@ -356,7 +356,9 @@ class _ContactQPOracle:
         reaches zero first (partial step: i leaves A; p stays the candidate).  z = 0 marks a row that
         depends on A: only partial steps are possible.  Every step increases the dual objective: finite, no
         cycling, no regularisation; dependent rows never enter A, so W_AA stays positive definite.
-        What the device runs for the *_EXACT contact models (csrc/contact_models.hpp)."""
+        What the device runs for the *_EXACT contact models (csrc/contact_models.hpp) -- there from a warm
+        start (a few projected sweeps guess A, rows with negative restricted multipliers are released until
+        the pair is valid), which shortens the path and leaves the unique primal solution unchanged."""
         Bn, nc, _ = W.shape
         ar = np.arange(Bn)
         Wd = np.einsum("bii->bi", W)
