@@ -75,6 +75,7 @@ typedef enum irs_model_id {
     , IRS_MODEL_PLANAR_HAND_EXACT = 8 /* IRS_MODEL_PLANAR_HAND with the step QP solved EXACTLY (dual active-set
                                  method, csrc/contact_models.hpp) -- what the reference's simulator does (Gurobi) --
                                  instead of by pgs_iters projected sweeps; same params (pgs_iters ignored)      */
+    , IRS_MODEL_BOX_PIVOT_EXACT = 9 /* IRS_MODEL_BOX_PIVOT with the step QP solved exactly, likewise           */
 } irs_model_id;
 
 /* Smoothing estimators.                                                         */

@@ -21,6 +21,7 @@ MODEL_BOX_PIVOT = 5
 MODEL_BOX_ON_BOX = 6
 MODEL_BOX_PUSH = 7
 MODEL_PLANAR_HAND_EXACT = 8
+MODEL_BOX_PIVOT_EXACT = 9
 SMOOTH_ZERO_ORDER_AB = 0
 SMOOTH_FIRST_ORDER = 1
 SMOOTH_ZERO_ORDER_B = 2

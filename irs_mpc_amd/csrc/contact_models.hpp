@@ -839,6 +839,15 @@ struct BoxPivotModel {
     }
 };
 
+// Box pivoting with its step QP solved EXACTLY (12 rows), like PlanarHandExactModel.
+struct BoxPivotExactModel : BoxPivotModel {
+    static constexpr bool EXACT = true;
+    template <typename S>
+    IRS_HD static void step(const ModelParams& p, const S* x_ext, const S* u, S* xn_ext) {
+        irs_contact_step<BoxPivotExactModel, S>(p, x_ext, u, xn_ext);
+    }
+};
+
 // examples/box_pushing/analysis/box_on_box.py:11-20 -- the reference's own 1-D statement of the scheme:
 // a stiffness-controlled point (gain k) commanded to u pushes a mass m that sits in front of it.
 //   x = [x_a, x_u], u = commanded x_a; params = {h, m, k, pgs_iters}

@@ -810,6 +810,7 @@ bool is_light(int model, int mode) {
         case IRS_MODEL_BOX_ON_BOX: return light_m<BoxOnBoxModel>(mode);
         case IRS_MODEL_BOX_PUSH: return light_m<BoxPushModel>(mode);
         case IRS_MODEL_PLANAR_HAND_EXACT: return light_m<PlanarHandExactModel>(mode);
+        case IRS_MODEL_BOX_PIVOT_EXACT: return light_m<BoxPivotExactModel>(mode);
     }
     return false;
 }

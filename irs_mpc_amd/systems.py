@@ -2,7 +2,7 @@
 import numpy as np
 
 from ._lib import (MODEL_BICYCLE, MODEL_BOX_ON_BOX, MODEL_BOX_PIVOT, MODEL_BOX_PUSH, MODEL_PENDULUM,
-                   MODEL_PLANAR_HAND, MODEL_PLANAR_HAND_EXACT,
+                   MODEL_BOX_PIVOT_EXACT, MODEL_PLANAR_HAND, MODEL_PLANAR_HAND_EXACT,
                    MODEL_QUADROTOR, MODEL_THREE_CART)
 from .dynamical_system import DynamicalSystem
 
@@ -182,8 +182,15 @@ class BoxPivotingDynamics(QuasistaticDeviceDynamics):
     u = commanded hand position.  Same contact scheme as the planar hand; parity UNPINNED."""
     device_model = MODEL_BOX_PIVOT
 
-    def __init__(self, h, mass=1.0, mu=0.5, pgs_iters=50):
+    def __init__(self, h, mass=1.0, mu=0.5, pgs_iters=50, contact_solver="pgs"):
         super().__init__()
+        if contact_solver not in ("pgs", "exact"):
+            raise ValueError("contact_solver must be 'pgs' or 'exact'")
+        if contact_solver == "exact":
+            if type(self).device_model != MODEL_BOX_PIVOT:
+                raise NotImplementedError("contact_solver='exact' is built for box_pivoting and planar_hand")
+            self.device_model = MODEL_BOX_PIVOT_EXACT
+        self.contact_solver = contact_solver
         self.h = h
         self.dim_x = 5
         self.dim_u = 2
@@ -230,8 +237,9 @@ class BoxPushingDynamics(BoxPivotingDynamics):
     trajectory to 3e-8 and `jacobian_xu` the recorded Jacobians to 5e-7."""
     device_model = MODEL_BOX_PUSH
 
-    def __init__(self, h=0.1, mass=5.0, inertia=1.0 / 6.0, mu=0.5, pgs_iters=50):
-        super().__init__(h, mass, mu, pgs_iters)
+    def __init__(self, h=0.1, mass=5.0, inertia=1.0 / 6.0, mu=0.5, pgs_iters=50, contact_solver="pgs"):
+        # (two contact rows: the sweeps + polish are exact here; no separate exact functor)
+        super().__init__(h, mass, mu, pgs_iters, contact_solver)
         self.g = 0.0             # box_pushing_setup.py:18
         self.inertia = inertia
         self.kp = 500.0          # box_pushing_setup.py:10

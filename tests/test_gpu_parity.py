@@ -867,6 +867,37 @@ def test_planar_hand_exact_solver_random_states(amd):
     assert np.abs(Jd - Jo).max() < 1e-5
 
 
+def test_box_pivot_exact_solver_random_states(amd):
+    """The 12-row box-pivoting step QP solved exactly on the device (IRS_MODEL_BOX_PIVOT_EXACT) == the
+    oracle's exact solve on 3000 random states incl. penetration, and through the f32 sample pass."""
+    from irs_mpc_amd import device as dev
+    from irs_mpc_amd._lib import SMOOTH_ZERO_ORDER_B
+    rng = np.random.default_rng(77)
+    N = 3000
+    BOX = orc.BoxPivotOracle
+    box = np.stack([rng.uniform(-0.5, 0.5, N), rng.uniform(0.45, 0.9, N), rng.uniform(-1, 1, N)], 1)
+    hand = np.stack([rng.uniform(-1.2, 1.2, N), rng.uniform(0.05, 1.5, N)], 1)
+    X = np.zeros((N, 5))
+    X[:, BOX.PERM] = np.hstack([box, hand])
+    sys_o = BOX(0.1, pgs_iters=0)
+    sys_d = amd.BoxPivotingDynamics(0.1, contact_solver="exact")
+    U = X[:, sys_o.indices_u_into_x] + rng.normal(0, 0.2, (N, 2))
+    want, got = sys_o.dynamics_batch(X, U), sys_d.dynamics_batch(X, U)
+    step = np.abs(want - X).max(1, keepdims=True).clip(1e-3)
+    assert np.isfinite(got).all() and (np.abs(got - want) <= 1e-7 * step + 1e-9).all()
+    T, Ns = 4, 1500
+    x0 = BOX.pack([0.0, 0.5, 0.0], [-0.6, 0.3])
+    u_trj = np.tile(x0[sys_o.indices_u_into_x], (T, 1)) + np.linspace(0, 1, T)[:, None] * np.array([0.1, 0.0])
+    x_trj = orc.rollout(sys_o, x0, u_trj)
+    du = (0.05 * rng.normal(size=(T, Ns, 2))).astype(np.float32)
+    o = sys_d.dm().smooth(SMOOTH_ZERO_ORDER_B, dev.to_dev(x_trj), dev.to_dev(u_trj), None, dev.to_dev(du, dev.F32))
+    Ao, Bo, co = orc.zero_order_B_decoupled(sys_o, x_trj, u_trj, du.astype(np.float64))
+    np.testing.assert_allclose(o["Bt"].cpu().numpy(), Bo, rtol=0, atol=2e-3)     # Kp = 5e4: f32 steps of a stiff hand
+    np.testing.assert_allclose(o["ct"].cpu().numpy(), co, rtol=0, atol=2e-3)
+    with pytest.raises(NotImplementedError):
+        amd.BoxPushingDynamics(0.1, contact_solver="exact")
+
+
 def test_capture_step_replays_the_two_launch_smoothing_step(amd):
     """irs_mpc_amd.distributed.capture_step (what bench.py times with several GPUs): the accumulate and
     solve launches of the sharded smoothing step captured into one HIP graph; replays reproduce the eagerly
