@@ -13,8 +13,18 @@ reports it too under "pendulum" so both kernels are tracked from one JSON line.
 
 A "step" = one smoothing pass over the (T x N) sample grid = ONE kernel launch on one GPU.  With
 --gpus N every rank holds its own N samples per timestep (weak scaling) and the (T,P) f64
-statistics are all-reduced (RCCL) inside every step, followed by the solve launch.  One process
-per GPU; N>1 is launched by torch.distributed.run.  Prints ONE JSON line on rank 0.
+statistics are all-reduced (RCCL) inside every step, followed by the solve launch -- the three
+launches replayed as one HIP graph.  One process per GPU; N>1 is launched by
+torch.distributed.run.  Prints ONE JSON line on rank 0 (stdout carries nothing else).
+
+iLQR iterations / s of the planar hand are measured on the optimisation run_planar_hand.py performs
+("ilqr_loop": 20 iterations per episode, every one re-linearised around the previous result with fresh
+device-drawn samples, trust region re-centred, first tail warm-started from the previous descent);
+"ilqr_first_iter_per_s" is the first iteration alone, repeated from a cold start.  The default run adds
+sub-reports: "first_order" (the reference's planar-hand gradient mode), "exact_contact_solver" (the step
+QP solved exactly), "pendulum" (configs[1]) and "cpu_baseline" (the oracle on one core and on a pool of
+16 worker processes, timed before the GPU is touched).  --mode first_order / --contact-solver exact make
+those the timed workload; --force-unfused times the multi-GPU step with a 1-rank RCCL group on one GPU.
 """
 import argparse
 import json
