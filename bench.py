@@ -361,22 +361,37 @@ def main():
             smooth_step, step_info["graph"] = launches, False
             if not args.no_graph and args.backend == "nccl":
                 # the three launches as one HIP graph: one host call per step
+                def agree(flag):
+                    """min over the ranks: every rank takes the same branch below (a rank that fell back alone
+                    would issue a different number of collectives and hang the others)"""
+                    if world == 1:
+                        return bool(flag)
+                    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cuda")
+                    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                    return bool(t.item())
+
+                torch.cuda.synchronize()
+                ref = [tv[k].clone() for k in ("At", "Bt", "ct")]
+                replay = None
                 try:
+                    replay = capture_step(launches)       # warm-up collectives run on every rank; the capture runs none
+                except Exception as e:      # noqa: BLE001 -- an RCCL build that cannot be captured
+                    step_info["graph_error"] = repr(e)[:200]
                     torch.cuda.synchronize()
-                    ref = [tv[k].clone() for k in ("At", "Bt", "ct")]
-                    replay = capture_step(launches)
+                if agree(replay is not None):
                     for k in ("At", "Bt", "ct"):
                         tv[k].zero_()
                     replay()
                     torch.cuda.synchronize()
                     # the replayed step must reproduce the eagerly issued one bit for bit (fixed-order sums)
-                    if all(torch.equal(a, tv[k]) for a, k in zip(ref, ("At", "Bt", "ct"))):
+                    same = all(torch.equal(a, tv[k]) for a, k in zip(ref, ("At", "Bt", "ct")))
+                    if agree(same):
                         smooth_step, step_info["graph"] = replay, True
                     else:
-                        step_info["graph_error"] = "replayed step differs from the eager one; eager step timed"
-                except Exception as e:      # noqa: BLE001 -- an RCCL build that cannot be captured
-                    step_info["graph_error"] = repr(e)[:200]
-                    torch.cuda.synchronize()
+                        step_info.setdefault("graph_error", "replayed step differs from the eager one on some rank; "
+                                                            "eager step timed")
+                elif "graph_error" not in step_info:
+                    step_info["graph_error"] = "capture failed on another rank; eager step timed"
 
         smooth_step()
         if w.name == "planar_hand":
