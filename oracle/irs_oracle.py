@@ -20,9 +20,13 @@ dependency that is not vendored and not installed; solve_tvlqr_qp() below
 restates the QP exactly as posed and solves its KKT system directly (valid while
 the box bounds are inactive), and the two *_exact.csv files anchor it.
 
-Quasistatic part -- the contact STEP is PINNED by simulator data the reference ships
-(examples/box_pushing/analysis/{xu,dxdu}_quasistatic.npy -> BoxPushOracle: 80-step trajectory and
-input Jacobians) and by the closed form of its 1-D case (box_on_box.py:11-20 -> BoxOnBoxOracle).
+Quasistatic part -- the contact STEP and its DERIVATIVE (jacobian_xu: the simulator's Dq_nextDq |
+Dq_nextDqa_cmd, i.e. gradient modes "exact" / "first_order") are PINNED by simulator data the reference
+ships (examples/box_pushing/analysis/{xu,dxdu}_quasistatic.npy -> BoxPushOracle: the 80-step trajectory to
+3e-8, all 80 Jacobians to 5e-7 but the contact-onset one) and by the closed form of its 1-D case
+(box_on_box.py:11-20 -> BoxOnBoxOracle).  The step QP's dual is solved by over-relaxed projected sweeps +
+an active-set polish (what the device runs by default) or exactly (pgs_iters = 0: dual active-set method,
+certified against the QP's KKT conditions).
 PARITY UNPINNED for the planar-hand / box-pivoting geometry and parameters (PlanarHandOracle,
 BoxPivotOracle) and for the *_quasistatic / ctrlbox_* functions: the reference steps pangtao22/quasistatic_simulator (external, not vendored, model
 files absent; plus Drake and Gurobi), so the contact step restates the published scheme
