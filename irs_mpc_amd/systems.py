@@ -141,7 +141,7 @@ class PlanarHandDynamics(QuasistaticDeviceDynamics):
     def __init__(self, h, mass=1.0, mu=0.5, pgs_iters=50, contact_solver="pgs"):
         """contact_solver: "pgs" = `pgs_iters` over-relaxed projected sweeps on the step QP's dual (fast,
         approximate when many contacts load the disc: DESIGN.md 7); "exact" = the dual active-set method
-        (what the reference's simulator does with Gurobi; 1.25x the time of the default, exact on every sample)."""
+        (what the reference's simulator does with Gurobi; 1.4x the time of the default, exact on every sample)."""
         super().__init__()
         if contact_solver not in ("pgs", "exact"):
             raise ValueError("contact_solver must be 'pgs' or 'exact'")
