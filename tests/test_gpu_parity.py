@@ -1303,6 +1303,51 @@ def test_box_pivot_quasistatic_iteration_vs_oracle(amd):
     assert dm.quasistatic_descent_supported(120, 2)
 
 
+@pytest.mark.parametrize("system,solver", [("planar_hand", "pgs"), ("planar_hand", "exact"),
+                                           ("box_pivoting", "pgs"), ("box_pivoting", "exact"), ("box_pushing", "pgs")])
+@pytest.mark.parametrize("T", [7, 16, 23])
+def test_quasistatic_descent_outputs_are_self_consistent(amd, system, solver, T):
+    """Whatever the model, the contact solver and the parity of the horizon: the trajectory the active-set
+    descent returns is a rollout of the device dynamics under the controls it returns, and the cost it
+    returns is eval_cost (irs_lqr_quasistatic.py:153-194) of exactly that trajectory -- values that live in
+    registers across the out-of-line contact step of every tail."""
+    from irs_mpc_amd import device as dev
+    rng = np.random.default_rng(T)
+    if system == "planar_hand":
+        sys_d = amd.PlanarHandDynamics(0.1, contact_solver=solver)
+        x0 = HAND.pack([0.0, 0.35, 0.0], [-np.pi / 4, -np.pi / 4], [np.pi / 4, np.pi / 4])
+        q = HAND_Q
+        goal = HAND.pack([0.3, -0.1, 0.5], [0, 0], [0, 0])
+        w, kind = 0.05, "abs"
+    else:
+        cls = amd.BoxPivotingDynamics if system == "box_pivoting" else amd.BoxPushingDynamics
+        sys_d = cls(0.1, contact_solver=solver)
+        x0 = orc.BoxPivotOracle.pack([0.0, 0.5, 0.0], [-0.62, 0.3] if system == "box_pivoting" else [0.0, -0.2])
+        q = orc.BoxPivotOracle.pack([5, 5, 50], [0, 0])
+        goal = orc.BoxPivotOracle.pack([0.5, 0.0 if system == "box_pivoting" else 0.5, -0.4], [0, 0])
+        w, kind = 0.04, "rel"
+    n, m = sys_d.dim_x, sys_d.dim_u
+    idx = sys_d.get_u_indices_into_x()
+    dm = sys_d.dm()
+    u_trj = np.tile(x0[idx], (T, 1)) + 0.02 * rng.normal(size=(T, m)).cumsum(0)
+    Q, Qd, R = np.diag(q), np.diag(10 * q), 5.0 * np.eye(m)
+    xd = np.tile(x0 + goal, (T + 1, 1))
+    x_trj = dm.rollout_cost(dev.to_dev(x0), dev.to_dev(u_trj), dev.to_dev(Q), dev.to_dev(R), dev.to_dev(xd))[0]
+    du = (0.1 * rng.normal(size=(T, 600, m))).astype(np.float32)
+    o = dm.smooth(2, x_trj, dev.to_dev(u_trj), None, dev.to_dev(du, dev.F32))
+    nom = x_trj[:-1].index_select(1, torch.as_tensor(idx, device=x_trj.device))
+    bounds = dict(u_lo=(nom - w).contiguous(), u_hi=(nom + w).contiguous()) if kind == "abs" else \
+        dict(du_lo=dev.to_dev(np.full((T, m), -w)), du_hi=dev.to_dev(np.full((T, m), w)))
+    out = dm.quasistatic_box_descent(o["At"], o["Bt"], o["ct"], dev.to_dev(Q), dev.to_dev(Qd), dev.to_dev(R),
+                                     dev.to_dev(xd), dev.to_dev(x0), solver=2, max_iter=2000, eps=1e-10, **bounds)
+    info = out["info"].cpu().numpy()
+    assert info[0] == 0 and info[2] == 0, info
+    xn, un = out["x_new"].cpu().numpy(), out["u_new"].cpu().numpy()
+    x_roll = dm.rollout_cost(dev.to_dev(x0), dev.to_dev(un), dev.to_dev(Q), dev.to_dev(R), dev.to_dev(xd))[0].cpu().numpy()
+    np.testing.assert_allclose(xn, x_roll, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(float(out["cost"].item()), orc.eval_cost_quasistatic(xn, un, xd, Q, Qd, R, idx), rtol=1e-10)
+
+
 def test_contact_model_sums_layout_vs_oracle(amd):
     """Contact models ship [Gram | z (f - xb)' | sum z] (include/irs_hip.h): the two-stage path
     (accumulate -> finalize), the fused launch and the oracle's restatement of the layout agree, in
