@@ -1,13 +1,12 @@
 #!/usr/bin/env python3
 """Headline benchmark: rollouts x timesteps / s of the randomised-smoothing pass
 (get_TV_matrices: sample pass + reduction + solve -> A_t,B_t,c_t) and iLQR iterations / s
-(that + TV-LQR backward pass + closed-loop rollout + cost).
+(that + the TV-LQR descent: T re-solved tail QPs + true-dynamics rollout + cost).
 
 Default workload = the configuration BASELINE.json's metric is quoted on: planar_hand
 (quasi-dynamic contact, irs_lqr_quasistatic), T=50, N=10000 u-perturbations per timestep PER
-GPU, zero-order-B smoothing, samples resident in HBM (f32).  `--workload pendulum` runs
-BASELINE configs[1] (pendulum zero-order AB, T=30, N=10000), the HBM-bound case; the default run
-reports it too under "pendulum" so both kernels are tracked from one JSON line.
+GPU, zero-order-B smoothing, every sample's step QP solved EXACTLY (what the reference's simulator
+does), samples resident in HBM (f32).
 
     python bench.py --gpus 1 --steps 2000 --warmup 200
 
@@ -17,18 +16,29 @@ statistics are all-reduced (RCCL) inside every step, followed by the solve launc
 launches replayed as one HIP graph.  One process per GPU; N>1 is launched by
 torch.distributed.run.  Prints ONE JSON line on rank 0 (stdout carries nothing else).
 
-iLQR iterations / s of the planar hand are measured on the optimisation run_planar_hand.py performs
-("ilqr_loop": 20 iterations per episode, every one re-linearised around the previous result with fresh
-device-drawn samples, trust region re-centred, first tail warm-started from the previous descent);
-"ilqr_first_iter_per_s" is the first iteration alone, repeated from a cold start.  The default run adds
-sub-reports: "first_order" (the reference's planar-hand gradient mode), "exact_contact_solver" (the step
-QP solved exactly), "pendulum" (configs[1]) and "cpu_baseline" (the oracle on one core and on a pool of
-16 worker processes, timed before the GPU is touched).  --mode first_order / --contact-solver exact make
-those the timed workload; --force-unfused times the multi-GPU step with a 1-rank RCCL group on one GPU.
+iLQR iterations / s of the contact workloads are measured on the optimisation the reference's script
+performs ("ilqr_loop": 20 iterations per episode, every one re-linearised around the previous result with
+fresh device-drawn samples, bounds re-centred, first tail warm-started from the previous descent);
+"ilqr_first_iter_per_s" is the first iteration alone, repeated from a cold start.
+
+Sub-reports of the default single-GPU run (all in the same JSON line):
+  "sweep_N"             the metric's workload at N = 1e3 and 1e5 (north_star's N points)
+  "first_order"         the reference's planar-hand gradient mode (planar_hand_setup.py:28)
+  "pgs_contact_solver"  the opt-in approximate step-QP solver (50 projected sweeps + polish)
+  "pendulum"            BASELINE configs[1]: zero-order AB, T=30, N=1e4 (the HBM-bound case)
+  "quadrotor"           BASELINE configs[2]: first-order, T=50, N=1e4 + on-device Riccati descent
+  "box_pivoting"        BASELINE configs[4] at its per-GPU size (T=80, N=5e4/8): iRS-LQR (zero-order-B,
+                        rate-limited descent) against CEM at the same simulator-step budget per iteration
+                        (batch_size = N): iterations / s and cost after k iterations for both
+  "cpu_baseline"        the oracle on the host: one core (bounded sample), and a pool of
+                        min(usable CPUs, T) single-threaded processes at the GPU leg's N; median of >= 5
+--mode first_order / --contact-solver pgs / --workload X make those the timed workload; --force-unfused
+times the multi-GPU step with a 1-rank RCCL group on one GPU.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -41,22 +51,56 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 VALU_F32_PEAK_TFLOPS = 157.3  # peak FP32 (vector), same guide
+SIMDS, CLOCK_GHZ, ISSUE_CYCLES = 1024, 2.4, 4     # 256 CUs x 4 SIMDs; max clock; cycles one wave's VALU
+#                                                   instruction holds its SIMD's issue (same guide, constants table)
+
+# Algorithmic flops of ONE u-perturbed contact step of the planar hand inside the sample pass
+# (csrc/contact_models.hpp).  In the u-only modes the state is not perturbed, so the
+# contact geometry (J, phi, W = J D^-1 J', 1/W_ii) is the SAME for every sample of a timestep: it is
+# loop-invariant (the compiler hoists it; the PMC instruction count confirms it) and NOT counted.
+#   r = phi - J D^-1 b: only the 4 actuated entries of b move      8 x 4 x 2 =   64
+#   one projected sweep over the 8 rows (residual form)                           152
+#   masked LDL' of the 8 x 8 dual Hessian + one solve on it            196 + 120 = 316
+#   slacks g = r + W lam                                                          128
+#   primal recovery q+ = q + D^-1 (J' lam - b)                          112 + 14 = 126
+#   zero-order-B statistics (Gram 10 + cross 28 FMAs)                              76
+#   first-order extras: 4 right-hand sides through the factor, J'Y, B, sum       1208
+_F = dict(r=64, sweep=152, ldl_solve=316, slack=128, primal=126, gram=76, first=1208, polish=470)
+
+
+def contact_flops_per_sample(solver, pgs_iters, first_order):
+    """(flops, formula).  "exact": the dual active-set loop runs a data-dependent number of steps after its
+    warm start (0-3 typical, ~500 flops each) and up to 3 repair rounds: only the work EVERY sample does is
+    counted -- 32 warm-up sweeps, one factorisation + solve, the slacks -- so the figure is a LOWER bound of
+    the algorithmic flops and roofline.frac a lower bound with it."""
+    tail = _F["primal"] + (_F["first"] if first_order else _F["gram"])
+    if solver == "exact":
+        f = _F["r"] + 32 * _F["sweep"] + _F["ldl_solve"] + _F["slack"] + tail
+        return f, "64 (r) + 32*152 (warm-up sweeps) + 316 (masked LDL' + solve) + 128 (slacks) + 126 (primal) + %s; " \
+                  "data-dependent active-set steps NOT counted (lower bound)" % ("1208 (derivative)" if first_order else "76 (Gram)")
+    f = _F["r"] + pgs_iters * _F["sweep"] + _F["polish"] + tail
+    return f, "64 (r) + %d*152 (sweeps) + 470 (polish) + 126 (primal) + %s" % (
+        pgs_iters, "1208 (derivative)" if first_order else "76 (Gram)")
 
 
 class Workload:
     """Everything that differs between the benchmarked configurations."""
 
-    def __init__(self, name, T=None, mode=None, host_only=False, contact_solver="pgs"):
+    def __init__(self, name, T=None, mode=None, host_only=False, contact_solver="exact"):
         self.name = name
         self.contact_solver = contact_solver
+        self.bounds = None                  # ("abs" | "rel", half width) of the quasistatic descent
+        self.std_x = 0.0
+        self.flops_per_sample, self.flops_formula = None, None
         if host_only:           # a CPU-baseline worker process: only what the oracle needs, no GPU library
             self._host_only(T, mode)
             return
-        from irs_mpc_amd import PendulumDynamics, PlanarHandDynamics
+        import irs_mpc_amd as amd
         from irs_mpc_amd import _lib
         if name == "pendulum":
+            # examples/pendulum/pendulum_zero_order.py:11-43 (BASELINE configs[1])
             self.T = T or 30
-            self.system = PendulumDynamics(0.05)
+            self.system = amd.PendulumDynamics(0.05)
             self.mode, self.mode_name = _lib.SMOOTH_ZERO_ORDER_AB, "ZERO_ORDER_AB"
             self.x0 = np.zeros(2)
             self.u_trj = np.tile(np.array([0.1]), (self.T, 1))
@@ -65,10 +109,20 @@ class Workload:
             self.std_x, self.std_u = 1.0, 1.0
             self.label = "pendulum zero-order smoothing (BASELINE configs[1])"
             self.kernel = "smooth_kernel<PendulumModel, ZERO_ORDER_AB>"
-            self.flops_per_sample = None
+        elif name == "quadrotor":
+            # examples/quadrotor/quadrotor_first_order.py:12-52 with T = 50 (BASELINE configs[2])
+            self.T = T or 50
+            self.system = amd.QuadrotorDynamics(0.05)
+            self.mode, self.mode_name = _lib.SMOOTH_FIRST_ORDER, "FIRST_ORDER"
+            from examples.problems import quadrotor as quadrotor_problem
+            _, p, _, _, _ = quadrotor_problem(self.T)
+            self.x0, self.u_trj, self.Q, self.Qd, self.R, self.xd = p.x0, p.u_trj_initial, p.Q, p.Qd, p.R, p.xd_trj
+            self.std_x, self.std_u = 0.1, 0.1
+            self.label = "quadrotor first-order smoothing + on-device Riccati descent (BASELINE configs[2])"
+            self.kernel = "smooth_kernel<QuadrotorModel, FIRST_ORDER>"
         elif name == "planar_hand":
             self.T = T or 50
-            self.system = PlanarHandDynamics(0.1, contact_solver=contact_solver)
+            self.system = amd.PlanarHandDynamics(0.1, contact_solver=contact_solver)
             self.mode, self.mode_name = _lib.SMOOTH_ZERO_ORDER_B, "ZERO_ORDER_B"
             # examples/planar_hand/run_planar_hand.py:31-44 (initial grasp), :113-131 (costs, goal)
             sd = self.system
@@ -79,26 +133,40 @@ class Workload:
             q = parts([1e-3, 1e-3, 10.0], [1e-3, 1e-3], [1e-3, 1e-3])
             self.Q, self.Qd, self.R = np.diag(q), np.diag(100 * q), 5.0 * np.eye(4)
             self.xd = np.tile(self.x0 + parts([0.3, -0.1, 0.5], [0, 0], [0, 0]), (self.T + 1, 1))
-            self.std_x, self.std_u = 0.0, 0.3          # run_planar_hand.py:146
-            self.label = "planar_hand quasi-dynamic contact, zero-order-B smoothing (the metric's config)"
-            self.kernel = "smooth_kernel<PlanarHandModel, ZERO_ORDER_B>"
-            # per one-step evaluation of the contact QP (csrc/contact_models.hpp):
-            # QP assembly ~1.5 kFLOP + 152 FLOP per projected sweep + the active-set polish (masked LDL' 196,
-            # one solve 120, W dl 128, tests ~26) + the Gram update
-            self.flops_per_sample = 1500 + 152 * int(self.system.pgs_iters) + 470 + 76
-            if mode == "first_order":
+            self.std_u = 0.3                            # run_planar_hand.py:146
+            self.std_schedule = lambda it: 0.3 / it ** 0.8          # :142-146
+            self.bounds = ("abs", 0.5 * sd.h)           # :138-139: u_bounds_abs = +-0.5 h
+            first = mode == "first_order"
+            if first:
                 # gradient_mode "first_order" (examples/planar_hand/planar_hand_setup.py:28): every sample's
-                # step is differentiated through its active constraints inside the sample pass -- masked
-                # LDL' of the 8x8 dual Hessian (196 FLOP), 4 right-hand sides (480), J'Y (448), B (56), sum (28)
+                # step is differentiated through its active constraints inside the sample pass
                 self.mode, self.mode_name = _lib.SMOOTH_FIRST_ORDER, "FIRST_ORDER"
-                self.label = "planar_hand quasi-dynamic contact, first-order smoothing (per-sample active-set derivative)"
-                self.kernel = "smooth_kernel<PlanarHandModel, FIRST_ORDER>"
-                self.flops_per_sample = 1500 + 152 * int(self.system.pgs_iters) + 470 + 1208
-            if contact_solver == "exact":
-                # the dual active-set solve takes a data-dependent number of steps: no fixed flop count
-                self.label += " [step QP solved exactly: dual active-set method]"
-                self.kernel = self.kernel.replace("PlanarHandModel", "PlanarHandExactModel")
-                self.flops_per_sample = None
+            model = "PlanarHandExactModel" if contact_solver == "exact" else "PlanarHandModel"
+            self.label = "planar_hand quasi-dynamic contact, %s smoothing, step QP %s" % (
+                "first-order (per-sample active-set derivative)" if first else "zero-order-B",
+                "solved exactly (dual active-set method)" if contact_solver == "exact"
+                else "by %d projected sweeps + polish (opt-in)" % int(sd.pgs_iters))
+            if not first and contact_solver == "exact":
+                self.label += " -- the metric's config"
+            self.kernel = "smooth_kernel<%s, %s>" % (model, self.mode_name)
+            self.flops_per_sample, self.flops_formula = contact_flops_per_sample(contact_solver, int(sd.pgs_iters), first)
+        elif name == "box_pivoting":
+            # examples/box_pivoting/run_box_pivoting.py:20-131 (BASELINE configs[4]: T = 80)
+            self.T = T or 80
+            from examples.run_quasistatic import box_problem
+            sd, x0, u0, Qd_, Qdd_, Rd_, xd = box_problem(self.T)
+            if contact_solver != "exact":
+                sd = amd.BoxPivotingDynamics(0.1, contact_solver=contact_solver)
+            self.system = sd
+            self.mode, self.mode_name = _lib.SMOOTH_ZERO_ORDER_B, "ZERO_ORDER_B"
+            self.idx = sd.get_u_indices_into_x()
+            self.x0, self.u_trj, self.xd = x0, u0, xd
+            self.Q, self.Qd, self.R = sd.get_Q_from_Q_dict(Qd_), sd.get_Q_from_Q_dict(Qdd_), sd.get_R_from_R_dict(Rd_)
+            self.std_schedule = lambda it: 0.1 ** (0.5 * it)        # :122-126
+            self.std_u = self.std_schedule(1)
+            self.bounds = ("rel", 0.15 * sd.h)          # :119-120: u_bounds_rel = +-0.15 h
+            self.label = "box_pivoting quasi-dynamic contact (12 contact rows), zero-order-B smoothing, step QP solved exactly"
+            self.kernel = "smooth_kernel<BoxPivotExactModel, ZERO_ORDER_B>"
         else:
             raise ValueError(name)
 
@@ -115,129 +183,216 @@ class Workload:
             self.std_u, self.mode_name = 0.3, "FIRST_ORDER" if mode == "first_order" else "ZERO_ORDER_B"
 
     def bytes_per_sample(self, n, m):
-        """the f32 perturbations are read once."""
-        return 4 * (m if self.name == "planar_hand" else n + m)
+        """the f32 perturbations are read once (u only in the u-only modes)."""
+        return 4 * (m if self.name in ("planar_hand", "box_pivoting") else n + m)
 
     def oracle(self):
         from oracle import irs_oracle as orc
-        return orc, (orc.PendulumOracle(0.05) if self.name == "pendulum" else orc.PlanarHandOracle(0.1))
+        if self.name == "pendulum":
+            return orc, orc.PendulumOracle(0.05)
+        return orc, orc.PlanarHandOracle(0.1, pgs_iters=0 if self.contact_solver == "exact" else 50)
 
 
+# ------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle, timed; never the target)
+# ------------------------------------------------------------------------------------------------
 def _cpu_problem(w, N):
-    """The bounded CPU sample of workload `w`: (one full pass as a callable over a range of timesteps,
-    samples per timestep, name of the oracle function)."""
+    """(one pass over a range of timesteps as a callable, name of the oracle function) at N samples."""
     orc, s = w.oracle()
     T = w.T
     rng = np.random.default_rng(0)
     x = orc.rollout(s, w.x0, w.u_trj)
     if w.name == "pendulum":
-        Ns = N
-        dx = rng.normal(size=(T, Ns, 2)).astype(np.float32).astype(np.float64)
-        du = rng.normal(size=(T, Ns, 1)).astype(np.float32).astype(np.float64)
+        dx = rng.normal(size=(T, N, 2)).astype(np.float32).astype(np.float64)
+        du = rng.normal(size=(T, N, 1)).astype(np.float32).astype(np.float64)
 
         def part(t0, t1):
             orc.zero_order_TV(s, x[t0:t1 + 1], w.u_trj[t0:t1], dx[t0:t1], du[t0:t1])
-        what = "oracle.zero_order_TV"
-    else:
-        Ns = min(N, 2000)       # the vectorised PGS loop costs ~ms per 1000 samples per timestep
-        du = (w.std_u * rng.normal(size=(T, Ns, 4))).astype(np.float32).astype(np.float64)
-        if w.mode_name == "FIRST_ORDER":
-            def part(t0, t1):
-                orc.first_order_B_decoupled(s, x[t0:t1 + 1], w.u_trj[t0:t1], du[t0:t1])
-            what = "oracle.first_order_B_decoupled"
-        else:
-            def part(t0, t1):
-                orc.zero_order_B_decoupled(s, x[t0:t1 + 1], w.u_trj[t0:t1], du[t0:t1])
-            what = "oracle.zero_order_B_decoupled"
-    return part, Ns, what
+        return part, "oracle.zero_order_TV"
+    du = (w.std_u * rng.normal(size=(T, N, 4))).astype(np.float32).astype(np.float64)
+    if w.mode_name == "FIRST_ORDER":
+        def part(t0, t1):
+            orc.first_order_B_decoupled(s, x[t0:t1 + 1], w.u_trj[t0:t1], du[t0:t1])
+        return part, "oracle.first_order_B_decoupled"
+
+    def part(t0, t1):
+        orc.zero_order_B_decoupled(s, x[t0:t1 + 1], w.u_trj[t0:t1], du[t0:t1])
+    return part, "oracle.zero_order_B_decoupled"
 
 
-def _pool_worker(args):
-    """One worker of the pooled CPU baseline: its share of the timesteps, `reps` times, one thread."""
-    name, T, mode, N, t0, t1, reps = args
+def _one_thread():
     os.environ["OMP_NUM_THREADS"] = "1"
     try:
         import threadpoolctl
-        threadpoolctl.threadpool_limits(1)
+        return threadpoolctl.threadpool_limits(1)
     except Exception:       # noqa: BLE001
-        pass
-    part, _, _ = _cpu_problem(Workload(name, T, mode, host_only=True), N)
-    t_start = time.perf_counter()
+        return None
+
+
+def _pool_worker(args):
+    """One worker of the pooled CPU baseline: its share of the timesteps, `reps` times, one thread.
+    Returns the per-repetition times."""
+    name, T, mode, solver, N, t0, t1, reps = args
+    _one_thread()
+    part, _ = _cpu_problem(Workload(name, T, mode, host_only=True, contact_solver=solver), N)
+    part(t0, t1)                                    # warm-up (imports, first-touch)
+    out = []
     for _ in range(reps):
+        ts = time.perf_counter()
         part(t0, t1)
-    return time.perf_counter() - t_start
+        out.append(time.perf_counter() - ts)
+    return out
 
 
-def cpu_baseline(w, N, seconds=12.0, pool_cores=16):
-    """The oracle (NumPy restatement with the reference's structure: Python loop over t, vectorised
-    dynamics_batch, SVD lstsq) timed on the GPU box's host on a bounded sample of the same workload:
-    on ONE core, and -- the honest analogue of the reference's 18-30 ZMQ worker processes, which split
-    the timesteps among themselves (irs_lqr_quasistatic.py:245-263) -- on a pool of `pool_cores`
-    single-threaded processes (the one-GPU box's CPU share).  Reported, never the target."""
-    import multiprocessing as mp
-    part, Ns, what = _cpu_problem(w, N)
-    T = w.T
-
-    def once():
-        part(0, T)
+def usable_cpus():
     try:
-        import threadpoolctl
-        limit = threadpoolctl.threadpool_limits(1)      # "cores": 1 means one BLAS thread too
+        return len(os.sched_getaffinity(0))
     except Exception:       # noqa: BLE001
-        limit = None
-    once()
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        once()
-        reps += 1
-        el = time.perf_counter() - t0
-        if el > seconds or reps >= 2000:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(w, N, budget_s=15.0, reps=5):
+    """The oracle (NumPy restatement with the reference's structure: Python loop over t, vectorised
+    dynamics_batch, lstsq) timed on the GPU box's host, same workload, supplied samples:
+      * ONE core (one BLAS thread): median of `reps` passes at N_1 = the largest of {N, N/2, N/5, N/10, ...}
+        whose pass fits budget_s / reps (the rate of this loop does not depend on N once N >~ 1e3:
+        it is per-sample work; the sample is stated);
+      * "pool": the honest analogue of the reference's 18-30 ZMQ worker processes, which split the
+        timesteps among themselves (irs_lqr_quasistatic.py:245-263) -- min(usable CPUs, T) single-threaded
+        processes, each with its share of the timesteps at the GPU leg's N; a repetition costs what its
+        slowest worker takes; median of `reps`.
+    Reported, never the target."""
+    import multiprocessing as mp
+    T = w.T
+    limit = _one_thread()
+    # size the single-core sample: time a small probe, scale
+    probe_N = min(N, 200 if w.name != "pendulum" else 2000)
+    part, what = _cpu_problem(w, probe_N)
+    part(0, T)
+    ts = time.perf_counter()
+    part(0, T)
+    per_sample = (time.perf_counter() - ts) / (probe_N * T)
+    N1 = N
+    for div in (1, 2, 5, 10, 20, 50, 100):
+        N1 = max(probe_N, N // div)
+        if per_sample * N1 * T * reps <= budget_s:
             break
+    part, what = _cpu_problem(w, N1)
+    part(0, T)
+    times = []
+    for _ in range(reps):
+        ts = time.perf_counter()
+        part(0, T)
+        times.append(time.perf_counter() - ts)
+    med = statistics.median(times)
     if limit is not None:
         limit.restore_original_limits()
-    out = {"value": T * Ns * reps / el, "unit": "rollouts*timesteps/s", "cores": 1, "kind": "port",
-           "sample": "%d passes of T=%d N=%d of the same workload (%s, supplied samples, 1 thread, %.1f s)"
-                     % (reps, T, Ns, what, el),
-           "host_cpus": os.cpu_count()}
-    # pooled: the timesteps dealt out to `cores` processes, each repeating its share `reps_p` times
-    cores = max(1, min(pool_cores, os.cpu_count() or 1, T))
+    out = {"value": T * N1 / med, "unit": "rollouts*timesteps/s", "cores": 1, "kind": "port",
+           "sample": "median of %d passes of T=%d N=%d of the same workload (%s, supplied samples, 1 thread, %.1f s "
+                     "per pass)%s" % (reps, T, N1, what, med,
+                                      "" if N1 == N else "; the GPU leg runs N=%d: per-sample work, the rate carries over" % N),
+           "host_cpus": os.cpu_count(), "usable_cpus": usable_cpus()}
+    cores = max(1, min(usable_cpus(), T))
     try:
-        reps_p = max(1, int(reps * 6.0 / max(el, 1e-9) * cores))          # ~6-8 s of work per worker
         bounds = [round(i * T / cores) for i in range(cores + 1)]
-        jobs = [(w.name, w.T, "first_order" if w.mode_name == "FIRST_ORDER" else None, N, bounds[i], bounds[i + 1], reps_p)
-                for i in range(cores) if bounds[i + 1] > bounds[i]]
+        span = max(bounds[i + 1] - bounds[i] for i in range(cores))
+        Np = N
+        for div in (1, 2, 5, 10, 20, 50, 100):          # keep a repetition of the slowest worker under ~3 s
+            Np = max(probe_N, N // div)
+            if per_sample * Np * span * 1.5 <= 3.0:
+                break
+        jobs = [(w.name, w.T, "first_order" if w.mode_name == "FIRST_ORDER" else None, w.contact_solver, Np,
+                 bounds[i], bounds[i + 1], reps) for i in range(cores) if bounds[i + 1] > bounds[i]]
         ctx = mp.get_context("spawn")
         t0 = time.perf_counter()
         with ctx.Pool(len(jobs)) as pool:
-            busy = pool.map_async(_pool_worker, jobs).get(timeout=180)
+            per_worker = pool.map_async(_pool_worker, jobs).get(timeout=240)
         wall = time.perf_counter() - t0
-        out["pool"] = {"value": T * Ns * reps_p / max(busy), "unit": "rollouts*timesteps/s", "cores": len(jobs),
-                       "sample": "%d passes of T=%d N=%d, timesteps dealt out to %d single-threaded processes; "
-                                 "slowest worker %.1f s (%.1f s with process start-up)"
-                                 % (reps_p, T, Ns, len(jobs), max(busy), wall)}
+        rep_times = [max(wk[r] for wk in per_worker) for r in range(reps)]
+        medp = statistics.median(rep_times)
+        out["pool"] = {"value": T * Np / medp, "unit": "rollouts*timesteps/s", "cores": len(jobs),
+                       "sample": "median of %d passes of T=%d N=%d, timesteps dealt out to %d single-threaded "
+                                 "processes (min(usable CPUs, T)); a pass = its slowest worker, %.2f s (%.1f s in all "
+                                 "with process start-up)" % (reps, T, Np, len(jobs), medp, wall)}
     except Exception as e:      # noqa: BLE001 -- the pooled figure is an extra; never fail the bench on it
         out["pool"] = {"error": repr(e)[:200]}
     return out
 
 
+def pmc_entry(w, N):
+    """The PMC passes of tools/profile_round.sh for this kernel (separate rocprofv3 --pmc runs of this same
+    command), as adopted into profiles/pmc_latest.json together with the commit they were taken at."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if not os.path.exists(path):
+        return None, None
+    allp = json.load(open(path))
+    tag = {"ZERO_ORDER_AB": "zero", "ZERO_ORDER_B": "zeroB", "FIRST_ORDER": "first"}[w.mode_name]
+    key = "%s_%s_T%d_N%d" % (w.name + ("_exact" if w.contact_solver == "exact" and w.name in ("planar_hand", "box_pivoting")
+                                       else ""), tag, w.T, N)
+    return allp.get(key), allp.get("_meta")
+
+
+def roofline(w, N, k_ms, nm):
+    alg_bytes = w.bytes_per_sample(*nm) * N * w.T      # per launch (per GPU)
+    hbm = alg_bytes / (k_ms * 1e-3) / 1e9
+    pmc, meta = pmc_entry(w, N)
+    traffic, issue = None, None
+    src = None
+    if pmc:
+        src = {"file": "profiles/pmc_latest.json", "profile": meta}
+        if "FETCH_SIZE_raw_avg" in pmc:
+            # HBM bytes per launch: FETCH_SIZE (KB) doubled as the gfx950 note of MI355X_MICROARCH.md prescribes
+            traffic = (2.0 * pmc["FETCH_SIZE_raw_avg"] + pmc.get("WRITE_SIZE_raw_avg", 0.0)) * 1024.0
+        if "SQ_INSTS_VALU_raw_avg" in pmc and pmc.get("kernel_avg_ns"):
+            # share of the chip's VALU issue slots the launch used, all from the profile (its own kernel time)
+            issue = {"frac": pmc["SQ_INSTS_VALU_raw_avg"] * ISSUE_CYCLES / SIMDS / CLOCK_GHZ / pmc["kernel_avg_ns"],
+                     "formula": "SQ_INSTS_VALU x %d cycles / %d SIMDs / %.1f GHz / kernel_avg_ns (both from the profile)"
+                                % (ISSUE_CYCLES, SIMDS, CLOCK_GHZ),
+                     "SQ_INSTS_VALU": pmc["SQ_INSTS_VALU_raw_avg"], "kernel_avg_ns": pmc["kernel_avg_ns"],
+                     "valu_insts_per_sample": pmc["SQ_INSTS_VALU_raw_avg"] * 64.0 / (N * w.T)}
+    r = {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
+         "traffic": traffic, "traffic_source": src,
+         "kernel": w.kernel + " (sample pass + reduction + solve, one launch)",
+         "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k_ms,
+         "formula": "achieved = %d B x N x T / avg_launch_ms" % w.bytes_per_sample(*nm),
+         "timing": "HIP event pair on the launch stream around the timed launches / launches"}
+    if w.flops_per_sample:
+        # the contact step is arithmetic on registers: the f32 vector rate is what bounds it
+        tf = w.flops_per_sample * N * w.T / (k_ms * 1e-3) / 1e12
+        r.update({"bound": "valu_f32", "achieved": tf, "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                  "frac": tf / VALU_F32_PEAK_TFLOPS, "alg_flops_per_launch": w.flops_per_sample * N * w.T,
+                  "flops_per_sample": w.flops_per_sample,
+                  "formula": "achieved = flops_per_sample x N x T / avg_launch_ms;  flops_per_sample = "
+                             + w.flops_formula + ";  the contact geometry of a timestep (J, phi, W) is loop-invariant in "
+                             "the u-only modes and not counted",
+                  "valu_issue_slots": issue,
+                  "hbm": {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
+                          "formula": "%d B x N x T / avg_launch_ms (SURVEY 8(d))" % w.bytes_per_sample(*nm)},
+                  "note": "no GEMM shape in a per-sample dual solve: the bound is the f32 vector rate, not HBM or "
+                          "MFMA; the HBM view of the same launch is under 'hbm', the measured share of VALU issue "
+                          "slots under 'valu_issue_slots'"})
+    return r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="default 2000 (planar_hand) / 20000 (pendulum)")
+    ap.add_argument("--steps", type=int, default=None, help="default 2000 (contact workloads) / 20000 (pendulum)")
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="planar_hand", choices=["planar_hand", "pendulum"])
+    ap.add_argument("--workload", default="planar_hand", choices=["planar_hand", "pendulum", "quadrotor", "box_pivoting"])
     ap.add_argument("--T", type=int, default=None)
     ap.add_argument("--N", type=int, default=10000, help="samples per timestep per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the pendulum (configs[1]) sub-report")
+    ap.add_argument("--no-secondary", action="store_true", help="skip every sub-report (timed workload only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="run all ranks on GPU 0 with gloo (exercises the N>1 code path on a 1-GPU box)")
-    ap.add_argument("--sweep", action="store_true", help="also time N=1e3,1e5,1e6 (extra keys)")
+    ap.add_argument("--sweep", action="store_true", help="also time N=1e6 for the pendulum (extra key)")
     ap.add_argument("--mode", default=None, choices=["first_order"],
                     help="planar_hand: gradient_mode first_order instead of zero_order_B as the timed workload")
-    ap.add_argument("--contact-solver", default="pgs", choices=["pgs", "exact"],
-                    help="planar_hand: 50 over-relaxed projected sweeps (default) or the exact dual active-set solve")
+    ap.add_argument("--contact-solver", default="exact", choices=["pgs", "exact"],
+                    help="contact workloads: the exact dual active-set solve of every step QP (default; the "
+                         "reference's semantics) or 50 over-relaxed projected sweeps + polish")
     ap.add_argument("--no-graph", action="store_true",
                     help="several ranks: issue the step's launches one by one instead of replaying a HIP graph")
     ap.add_argument("--force-unfused", action="store_true",
@@ -261,8 +416,10 @@ def main():
     # the CPU baseline runs FIRST, before this process initialises the GPU: its pooled leg starts worker
     # processes (fresh interpreters), which a process that already holds the GPU must not do on this pool
     cpu_base = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.force_unfused:
-        cpu_base = cpu_baseline(Workload(args.workload, args.T, args.mode, host_only=True), args.N)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.force_unfused \
+            and args.workload in ("planar_hand", "pendulum"):
+        cpu_base = cpu_baseline(Workload(args.workload, args.T, args.mode, host_only=True,
+                                         contact_solver=args.contact_solver), args.N)
     if args.rehearse_one_gpu:       # testing aid: every rank on GPU 0, gloo collectives
         local, args.backend = 0, "gloo"
     torch.cuda.set_device(local)
@@ -323,7 +480,18 @@ def main():
 
     step_info = {}
 
-    def run(w, N, steps, warmup):
+    def bound_rows(w, x_trj, idx_t):
+        """Absolute bound rows of the quasistatic descent around the nominal trajectory x_trj
+        (irs_lqr_quasistatic.py:303-325)."""
+        kind, wd = w.bounds
+        if kind == "abs":
+            nom = x_trj[:-1].index_select(1, idx_t)
+            return dict(u_lo=(nom - wd).contiguous(), u_hi=(nom + wd).contiguous())
+        m = idx_t.numel()
+        return dict(du_lo=torch.full((w.T, m), -wd, dtype=dev.F64, device=x_trj.device),
+                    du_hi=torch.full((w.T, m), wd, dtype=dev.F64, device=x_trj.device))
+
+    def run(w, N, steps, warmup, loop_iters=20):
         """Times the smoothing step and the full iLQR iteration of workload `w`."""
         dm = w.system.dm()
         n, m, T, MODE = dm.n, dm.m, w.T, w.mode
@@ -332,10 +500,11 @@ def main():
         x_trj, _ = dm.rollout_cost(x0, u_trj, Q, R, xd)
         g = torch.Generator(device="cuda").manual_seed(1234 + rank)
         dx = None
-        if w.name == "pendulum":
+        if w.std_x > 0:
             dx = w.std_x * torch.randn((T, N, n), generator=g, device="cuda", dtype=torch.float32)
         du = w.std_u * torch.randn((T, N, m), generator=g, device="cuda", dtype=torch.float32)
         n_total = N * world
+        contact = w.bounds is not None
         if not unfused:
             plan = dev.SmoothPlan(dm, MODE, x_trj, u_trj, dx=dx, du=du, fuse=True)
             tv = plan.out
@@ -394,18 +563,18 @@ def main():
                     step_info["graph_error"] = "capture failed on another rank; eager step timed"
 
         smooth_step()
-        if w.name == "planar_hand":
-            # IrsLqrQuasistatic.local_descent (irs_lqr_quasistatic.py:286-345) as run_planar_hand.py
-            # sets it up: du cost, trust region u_bounds_abs = +-0.5 h around the nominal actuated
-            # positions (:138-139), T re-solved tail QPs, contact dynamics in the loop; one launch
-            nom = x_trj[:-1].index_select(1, torch.as_tensor(w.idx, device=x_trj.device))
-            u_lo, u_hi = (nom - 0.5 * w.system.h).contiguous(), (nom + 0.5 * w.system.h).contiguous()
+        if contact:
+            # IrsLqrQuasistatic.local_descent (irs_lqr_quasistatic.py:286-345) as the reference's script sets
+            # it up: du cost, ONE control box (trust region / rate limit), T re-solved tail QPs, contact
+            # dynamics in the loop; one launch
+            idx_t = torch.as_tensor(w.idx, device=x_trj.device)
+            brows = bound_rows(w, x_trj, idx_t)
             qs_out = {}
 
             def descent_run():
                 qs_out["o"] = dm.quasistatic_box_descent(tv["At"], tv["Bt"], tv["ct"], Q, Qd, R, xd, x0,
-                                                         u_lo=u_lo, u_hi=u_hi, solver=0, max_iter=2000,
-                                                         eps=1e-9, out=qs_out.get("o"))
+                                                         solver=0, max_iter=2000, eps=1e-9, out=qs_out.get("o"),
+                                                         **brows)
         else:
             descent = dev.DescentPlan(dm, tv["At"], tv["Bt"], tv["ct"], Q, Qd, R, xd, x0)
 
@@ -417,19 +586,17 @@ def main():
             descent_run()
 
         el, ev_ms = timed(smooth_step, steps, warmup)
-        it_steps = max(1, steps // (4 if w.name == "pendulum" else 20))
+        it_steps = max(1, steps // (20 if contact else 4))
         el_it, _ = timed(ilqr_step, it_steps, max(1, it_steps // 10))
         el_it *= steps / it_steps
         loop = None
-        if w.name == "planar_hand":
-            # The optimisation run_planar_hand.py performs: num_iters = 20 iterations
-            # (planar_hand_setup.py:36), every one linearised around the previous one's result with FRESH
-            # samples of std 0.3 / iter^0.8 (run_planar_hand.py:142-146; drawn on the device), the trust
-            # region re-centred on the new nominal, and the first tail's active set handed on from the
-            # previous descent (irs_quasistatic_box_descent_ws) -- cold at the start of every episode.
-            # Nothing returns to the host inside an episode.
-            K_LOOP = 20
-            idx_t = torch.as_tensor(w.idx, device=x_trj.device)
+        if contact:
+            # The optimisation the reference's script performs: `loop_iters` iterations (planar_hand_setup.py:36
+            # num_iters = 20), every one linearised around the previous one's result with FRESH samples of the
+            # script's std schedule (drawn on the device), the bounds re-centred on the new nominal, and the
+            # first tail's active set handed on from the previous descent (irs_quasistatic_box_descent_ws) --
+            # cold at the start of every episode.  Nothing returns to the host inside an episode.
+            K_LOOP = loop_iters
             rngd = dict(N=N, std_x=None, std_u=[w.std_u] * m, seed=4321, iter=1)
             xs = [x_trj.clone(), torch.empty_like(x_trj)]
             us = [u_trj.clone(), torch.empty_like(u_trj)]
@@ -450,7 +617,7 @@ def main():
                 del lcost[:]
                 for it in range(1, K_LOOP + 1):
                     a_, b_ = (it - 1) % 2, it % 2
-                    lplan.set_iter(it, None, [w.std_u / it ** 0.8] * m)
+                    lplan.set_iter(it, None, [w.std_schedule(it)] * m)
                     lplan.set_trajectory(xs[a_], us[a_])
                     lplan.run()
                     if not unfused:
@@ -463,10 +630,9 @@ def main():
                         ltv["out"] = dm.smooth_finalize(MODE, n_total, xs[a_], us[a_], lplan.sums,
                                                         out=ltv.get("out"), workspace=lplan.ws)
                         At_, Bt_, ct_ = ltv["out"][:3]
-                    nom_ = xs[a_][:-1].index_select(1, idx_t)
-                    louts[b_] = dm.quasistatic_box_descent(At_, Bt_, ct_, Q, Qd, R, xd, x0,
-                                                           u_lo=nom_ - 0.5 * w.system.h, u_hi=nom_ + 0.5 * w.system.h,
-                                                           solver=0, max_iter=2000, eps=1e-9, out=louts[b_], act=act)
+                    louts[b_] = dm.quasistatic_box_descent(At_, Bt_, ct_, Q, Qd, R, xd, x0, solver=0, max_iter=2000,
+                                                           eps=1e-9, out=louts[b_], act=act,
+                                                           **bound_rows(w, xs[a_], idx_t))
                     xs[b_], us[b_] = louts[b_]["x_new"], louts[b_]["u_new"]
                     lcost.append(louts[b_]["cost"].clone())
 
@@ -480,12 +646,11 @@ def main():
                     "descends": bool(min(costs) < 0.9 * costs[0]),
                     "qp_converged_last_iteration": bool(qi[0] == 0 and qi[2] == 0),
                     "iterations_per_episode": K_LOOP, "episodes": n_ep,
-                    "cost_first_iteration": costs[0], "cost_best": min(costs),
-                    "what": "the 20-iteration optimisation of run_planar_hand.py from its initial trajectory: every "
+                    "cost_first_iteration": costs[0], "cost_best": min(costs), "cost_last": costs[-1],
+                    "what": "the %d-iteration optimisation of the reference's script from its initial trajectory: every "
                             "iteration re-linearises around the previous result with fresh device-drawn samples "
-                            "(std 0.3/iter^0.8), re-centres the trust region and warm-starts the first tail's active "
-                            "set from the previous descent; cold start at the head of each episode"}
-        if w.name == "planar_hand":
+                            "(the script's std schedule), re-centres the bounds and warm-starts the first tail's active "
+                            "set from the previous descent; cold start at the head of each episode" % K_LOOP}
             qi = qs_out["o"]["info"].cpu().numpy()
             assert qi[0] == 0 and qi[2] == 0, "bounded TV-LQR did not converge: %s" % qi
         # Kernel time of the sample pass: HIP events recorded on the stream the kernel is
@@ -504,42 +669,53 @@ def main():
             torch.cuda.synchronize()
             k_ms = e0.elapsed_time(e1) / steps
         info = int(tv["info"].abs().sum().item())
-        assert info == 0, "smoothing solve reported a non-SPD Gram matrix"
+        assert info == 0, "smoothing solve reported a non-SPD Gram matrix or a non-finite statistic"
         return el, el_it, k_ms, (n, m), loop
 
-    def roofline(w, N, k_ms, nm):
-        alg_bytes = w.bytes_per_sample(*nm) * N * w.T      # per launch (per GPU)
-        hbm = alg_bytes / (k_ms * 1e-3) / 1e9
-        # HBM traffic per launch from the PMC passes of tools/profile_round.sh (separate rocprofv3
-        # --pmc runs of this same command; FETCH_SIZE doubled as the gfx950 note in
-        # MI355X_MICROARCH.md prescribes).
-        traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc_path):
-            tag = {"ZERO_ORDER_AB": "zero", "ZERO_ORDER_B": "zeroB", "FIRST_ORDER": "first"}[w.mode_name]
-            key = "%s_%s_T%d_N%d" % (w.name + ("_exact" if getattr(w, "contact_solver", "pgs") == "exact" else ""),
-                                     tag, w.T, N)
-            pmc = json.load(open(pmc_path)).get(key)
-            if pmc and "FETCH_SIZE_raw_avg" in pmc:
-                traffic = (2.0 * pmc["FETCH_SIZE_raw_avg"] + pmc.get("WRITE_SIZE_raw_avg", 0.0)) * 1024.0
-                traffic_src = "profiles/pmc_latest.json"
-        r = {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
-             "traffic": traffic, "traffic_source": traffic_src,
-             "kernel": w.kernel + " (sample pass + reduction + solve, one launch)",
-             "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": k_ms,
-             "timing": "HIP event pair on the launch stream around the timed launches / launches"}
-        if w.flops_per_sample:
-            # the contact step is arithmetic on registers (PGS sweeps): f32 VALU is what bounds it
-            tf = w.flops_per_sample * N * w.T / (k_ms * 1e-3) / 1e12
-            r.update({"bound": "valu_f32", "achieved": tf, "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                      "frac": tf / VALU_F32_PEAK_TFLOPS, "alg_flops_per_launch": w.flops_per_sample * N * w.T,
-                      "hbm": {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS},
-                      "note": "no GEMM shape in a per-sample projected Gauss-Seidel solve: the bound is the f32 "
-                              "vector rate, not HBM or MFMA; the HBM view of the same launch is under 'hbm'"})
+    def sub_report(w_, N_, steps_, warm_=None, **kw):
+        e, ei, km, nm_, lp = run(w_, N_, steps_, warm_ if warm_ is not None else max(1, steps_ // 10), **kw)
+        r = {"config": {"workload": w_.label, "T": w_.T, "N_per_gpu": N_, "mode": w_.mode_name},
+             "value": N_ * w_.T * steps_ / e, "unit": "rollouts*timesteps/s", "steps": steps_,
+             "ms_per_step": 1e3 * e / steps_, "avg_launch_ms": km,
+             "ilqr_iters_per_s": lp["iters_per_s"] if lp else steps_ / ei,
+             "ilqr_first_iter_per_s": steps_ / ei, "roofline": roofline(w_, N_, km, nm_)}
+        if lp:
+            r["ilqr_loop"] = lp
         return r
+
+    def run_cem(w, B, iters, n_ep=2):
+        """CrossEntropyMethodQuasistatic.local_descent (cem_quasistatic.py:168-211) at batch_size = B: B contact
+        rollouts of T steps + their quasistatic costs, the elites, the refit -- `iters` iterations per episode
+        from the script's initial trajectory; candidates drawn on the device (synthetic data)."""
+        dm = w.system.dm()
+        T, m = w.T, dm.m
+        Q, Qd, R = dev.to_dev(w.Q), dev.to_dev(w.Qd), dev.to_dev(w.R)
+        xd, x0, u0 = dev.to_dev(w.xd), dev.to_dev(w.x0), dev.to_dev(w.u_trj)
+        n_elite = max(2, B // 20)                                   # run_box_pivoting_cem.py:118-119: 5 of 100
+        gen = torch.Generator(device="cuda").manual_seed(99)
+        best = []
+
+        def episode():
+            u, std = u0.clone(), torch.full((T, m), 0.2, dtype=dev.F64, device="cuda")      # :120 initial_std
+            del best[:]
+            for _ in range(iters):
+                cand = u[None] + std[None] * torch.randn((B, T, m), generator=gen, device="cuda", dtype=dev.F64)
+                costs = dm.cem_rollout_costs_quasistatic(cand, x0, Q, Qd, R, xd)
+                _, u, std = dm.cem_refit(cand, costs, n_elite)
+                best.append(dm.cem_rollout_costs_quasistatic(u[None].contiguous(), x0, Q, Qd, R, xd))
+
+        el, _ = timed(episode, n_ep, 1, prewarm=1)
+        costs = [float(c.item()) for c in best]
+        return {"iters_per_s": n_ep * iters / el, "ms_per_iter": 1e3 * el / (n_ep * iters), "batch_size": B,
+                "n_elite": n_elite, "initial_std": 0.2, "iterations_per_episode": iters,
+                "cost_after_k_iterations": costs[-1], "cost_best": min(costs),
+                "sim_steps_per_iteration": B * T,
+                "what": "CEM (cem_quasistatic.py:168-211) at batch_size = N: the same number of simulator steps per "
+                        "iteration as the iRS-LQR sample pass; the mean's cost after each refit"}
 
     w = Workload(args.workload, args.T, args.mode, contact_solver=args.contact_solver)
     N, T = args.N, w.T
+    contact = w.bounds is not None
     el, el_it, k_mean, nm, loop = run(w, N, args.steps, args.warmup)
     out = {
         "metric": "rollouts*timesteps/s (randomized-smoothing pass) + iLQR-iters/s",
@@ -547,9 +723,15 @@ def main():
         "unit": "rollouts*timesteps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * el / args.steps,
+        "timed_region_s": el,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "parity": ("partial: the contact STEP and its derivative are pinned by the simulator data the reference ships "
+                   "(box_pushing) and the optimiser around them by the reference's result files; the planar-hand / "
+                   "box-pivoting geometry and parameters (mass, friction) are NOT pinned -- the simulator's model files "
+                   "are absent (DESIGN.md 3)") if contact else "pinned by reference-run fixtures and result files",
         "config": {"workload": w.label, "T": T, "N_per_gpu": N, "N_total": N * world, "mode": w.mode_name,
+                   "contact_solver": w.contact_solver if contact else None,
                    "samples": "supplied, resident in HBM (f32)",
                    "parallelism": "samples sharded over %d GPU(s), 1 all-reduce of (T,P) f64 per step" % world},
         "ilqr_iters_per_s": loop["iters_per_s"] if loop else args.steps / el_it,
@@ -559,10 +741,9 @@ def main():
         "ilqr_iters_note": ("ilqr_iters_per_s = the real 20-iteration loop (ilqr_loop); ilqr_first_iter_per_s = the "
                             "first iteration alone, repeated from a cold start (no warm start, supplied samples)"
                             if loop else "one iteration repeated: its cost does not depend on the trajectory"),
-        "ilqr_iter": ("smoothing launch + IrsLqrQuasistatic.local_descent (du cost, u_bounds_abs = +-0.5h trust "
-                      "region, T re-solved tail QPs by the active-set solver, contact dynamics in the loop)"
-                      if w.name == "planar_hand" else
-                      "smoothing launch + Riccati + closed-loop rollout + cost (bounds inactive)"),
+        "ilqr_iter": ("smoothing launch + IrsLqrQuasistatic.local_descent (du cost, one control box, T re-solved tail "
+                      "QPs by the active-set solver, contact dynamics in the loop)"
+                      if contact else "smoothing launch + Riccati + closed-loop rollout + cost (bounds inactive)"),
         "roofline": roofline(w, N, k_mean, nm),
     }
     if unfused:
@@ -571,43 +752,46 @@ def main():
                                  "accumulate launch + all-reduce + solve launch, issued one by one")
         if "graph_error" in step_info:
             out["config"]["graph_error"] = step_info["graph_error"]
-    if args.sweep and world == 1:
+    secondary = world == 1 and not unfused and not args.no_secondary
+    if secondary:
+        # north_star's N points for the timed workload
         sweep = {}
-        for Ns in (1000, 100000) + ((1000000,) if w.name == "pendulum" else ()):
-            st = max(20, args.steps // (4 if Ns <= 100000 else 16))
-            e, ei, km, _, _ = run(w, Ns, st, 5)
-            sweep[str(Ns)] = {"value": Ns * T * st / e, "ilqr_iters_per_s": st / ei,
-                              "kernel_GBps": w.bytes_per_sample(*nm) * Ns * T / (km * 1e-3) / 1e9}
+        for Ns in (1000, 100000) + ((1000000,) if (args.sweep and w.name == "pendulum") else ()):
+            st = max(20, args.steps // (4 if Ns <= 10000 else 16))
+            e, ei, km, _, lp = run(w, Ns, st, max(2, st // 10), loop_iters=20)
+            sweep[str(Ns)] = {"value": Ns * T * st / e, "ms_per_step": 1e3 * e / st, "avg_launch_ms": km,
+                              "ilqr_iters_per_s": lp["iters_per_s"] if lp else st / ei,
+                              "hbm_GBps": w.bytes_per_sample(*nm) * Ns * T / (km * 1e-3) / 1e9,
+                              "valu_TFLOPs": (w.flops_per_sample * Ns * T / (km * 1e-3) / 1e12) if w.flops_per_sample else None}
         out["sweep_N"] = sweep
-    if world == 1 and not unfused and not args.no_secondary and w.name == "planar_hand" and args.mode is None:
+    if secondary and w.name == "planar_hand" and args.mode is None and args.contact_solver == "exact":
+        st = max(20, args.steps // 2)
         # the reference's planar_hand set-up runs gradient_mode "first_order" (planar_hand_setup.py:28)
-        w1 = Workload("planar_hand", args.T, "first_order")
-        st1 = max(20, args.steps // 2)
-        e1, ei1, km1, nm1, loop1 = run(w1, N, st1, max(1, st1 // 10))
-        out["first_order"] = {"config": {"workload": w1.label, "T": w1.T, "N_per_gpu": N, "mode": w1.mode_name},
-                              "value": N * w1.T * st1 / e1, "unit": "rollouts*timesteps/s", "steps": st1,
-                              "ms_per_step": 1e3 * e1 / st1, "ilqr_iters_per_s": loop1["iters_per_s"],
-                              "ilqr_loop": loop1, "ilqr_first_iter_per_s": st1 / ei1,
-                              "roofline": roofline(w1, N, km1, nm1)}
-    if world == 1 and not unfused and not args.no_secondary and w.name == "planar_hand" and args.mode is None \
-            and args.contact_solver == "pgs":
-        # the same workload with the step QP solved exactly (IRS_MODEL_PLANAR_HAND_EXACT)
-        wx = Workload("planar_hand", args.T, None, contact_solver="exact")
-        stx = max(20, args.steps // 4)
-        ex_, eix, kmx, nmx, loopx = run(wx, N, stx, max(1, stx // 10))
-        out["exact_contact_solver"] = {"config": {"workload": wx.label, "T": wx.T, "N_per_gpu": N, "mode": wx.mode_name},
-                                       "value": N * wx.T * stx / ex_, "unit": "rollouts*timesteps/s", "steps": stx,
-                                       "ms_per_step": 1e3 * ex_ / stx, "avg_launch_ms": kmx,
-                                       "ilqr_iters_per_s": loopx["iters_per_s"], "ilqr_loop": loopx,
-                                       "ilqr_first_iter_per_s": stx / eix}
-    if world == 1 and not unfused and not args.no_secondary and w.name != "pendulum":
-        w2 = Workload("pendulum")
-        st2 = 10000
-        e2, ei2, km2, nm2, _ = run(w2, N, st2, 1000)
-        out["pendulum"] = {"config": {"workload": w2.label, "T": w2.T, "N_per_gpu": N, "mode": w2.mode_name},
-                           "value": N * w2.T * st2 / e2, "unit": "rollouts*timesteps/s", "steps": st2,
-                           "ms_per_step": 1e3 * e2 / st2, "ilqr_iters_per_s": st2 / ei2,
-                           "roofline": roofline(w2, N, km2, nm2)}
+        out["first_order"] = sub_report(Workload("planar_hand", args.T, "first_order"), N, st)
+        # the opt-in approximate step-QP solver
+        out["pgs_contact_solver"] = sub_report(Workload("planar_hand", args.T, None, contact_solver="pgs"), N,
+                                               max(20, args.steps // 4))
+    if secondary and w.name != "pendulum":
+        out["pendulum"] = sub_report(Workload("pendulum"), 10000, max(200, 5 * args.steps), 1000)
+    if secondary and w.name != "quadrotor":
+        out["quadrotor"] = sub_report(Workload("quadrotor"), 10000, max(100, args.steps))
+    if secondary and w.name != "box_pivoting":
+        # BASELINE configs[4]: T = 80, N = 5e4 over 8 GPUs -> 6250 samples per timestep per GPU
+        wb = Workload("box_pivoting")
+        Nb = 50000 // 8
+        K = 10
+        rb = sub_report(wb, Nb, max(20, args.steps // 4), loop_iters=K)
+        rb["config"]["N_total_at_8_gpus"] = 50000
+        rb["cem_same_budget"] = run_cem(wb, Nb, K)
+        lp = rb.get("ilqr_loop") or {}
+        rb["comparison"] = {"budget_sim_steps_per_iteration": Nb * wb.T, "iterations": K,
+                            "irs_lqr": {"iters_per_s": lp.get("iters_per_s"), "cost_after_k_iterations": lp.get("cost_last"),
+                                        "cost_best": lp.get("cost_best")},
+                            "cem": {"iters_per_s": rb["cem_same_budget"]["iters_per_s"],
+                                    "cost_after_k_iterations": rb["cem_same_budget"]["cost_after_k_iterations"],
+                                    "cost_best": rb["cem_same_budget"]["cost_best"]},
+                            "ref": "examples/box_pivoting/run_box_pivoting.py:96-135 vs run_box_pivoting_cem.py:100-135"}
+        out["box_pivoting"] = rb
     if rank == 0:
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base

@@ -76,6 +76,7 @@ typedef enum irs_model_id {
                                  method, csrc/contact_models.hpp) -- what the reference's simulator does (Gurobi) --
                                  instead of by pgs_iters projected sweeps; same params (pgs_iters ignored)      */
     , IRS_MODEL_BOX_PIVOT_EXACT = 9 /* IRS_MODEL_BOX_PIVOT with the step QP solved exactly, likewise           */
+    , IRS_MODEL_BOX_PUSH_EXACT = 10 /* IRS_MODEL_BOX_PUSH with the step QP solved exactly, likewise            */
 } irs_model_id;
 
 /* Smoothing estimators.                                                         */
@@ -108,6 +109,15 @@ int irs_dynamics_batch(int model, const double *params, int n_params,
  * QuasistaticDynamics.jacobian_xu (irs_lqr/quasistatic_dynamics.py:184-191).           */
 int irs_jacobian_xu_batch(int model, const double *params, int n_params,
                           const double *X, const double *U, int B, double *J, void *stream);
+
+/* Per-sample view of calc_AB_first_order on a contact model (irs_lqr/quasistatic_dynamics.py:193-208: the loop
+ * body, one u-perturbation per lane): from the nominal x (n), u (m) DEV f64 and du (B,m) DEV f32, exactly what a
+ * lane of the FIRST_ORDER sample pass evaluates in f32 -- Xn (B,n) the step from ((float)x, (float)u + du[b]),
+ * Bs (B,n,m) the block Dq_nextDqa_cmd of its active-set derivative, active_mask (B) i32 bit i = contact row i
+ * active.  Diagnostics: lets a test separate the samples whose active set differs between the f32 lanes and an
+ * f64 evaluation from the rest.  IRS_ERR_UNSUPPORTED for analytic models.                                   */
+int irs_contact_samples_f32(int model, const double *params, int n_params, const double *x, const double *u,
+                            const float *du, int B, float *Xn, float *Bs, int *active_mask, void *stream);
 
 /* IrsLqr.rollout + evaluate_cost (irs_lqr/irs_lqr.py:105-119, :121-137).
  * x0 (n), u_trj (T,m), Q (n,n), R (m,m), xd_trj (T+1,n) DEV f64 in;

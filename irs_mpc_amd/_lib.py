@@ -22,6 +22,7 @@ MODEL_BOX_ON_BOX = 6
 MODEL_BOX_PUSH = 7
 MODEL_PLANAR_HAND_EXACT = 8
 MODEL_BOX_PIVOT_EXACT = 9
+MODEL_BOX_PUSH_EXACT = 10
 SMOOTH_ZERO_ORDER_AB = 0
 SMOOTH_FIRST_ORDER = 1
 SMOOTH_ZERO_ORDER_B = 2
@@ -35,6 +36,7 @@ SIGNATURES = {
     "irs_model_info": (c_int, [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "irs_dynamics_batch": (c_int, [c_int, POINTER(c_double), c_int, _dp, _dp, c_int, _dp, c_void_p]),
     "irs_jacobian_xu_batch": (c_int, [c_int, POINTER(c_double), c_int, _dp, _dp, c_int, _dp, c_void_p]),
+    "irs_contact_samples_f32": (c_int, [c_int, POINTER(c_double), c_int, _dp, _dp, _dp, c_int, _dp, _dp, _dp, c_void_p]),
     "irs_rollout_cost": (c_int, [c_int, POINTER(c_double), c_int, c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, c_void_p]),
     "irs_evaluate_cost": (c_int, [c_int, c_int, c_int, _dp, _dp, _dp, _dp, _dp, _dp, c_void_p]),
     "irs_sums_len": (c_int, [c_int, c_int]),

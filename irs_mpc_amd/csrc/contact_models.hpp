@@ -579,14 +579,23 @@ IRS_HD void irs_contact_step(const ModelParams& p, const S* x_ext, const S* u, S
 
 // The step and its active-set derivative in the reference's x order: Bext (NX x NU, row-major) and,
 // WITH_A, Aext (NX x NX).
+// `active_mask` (optional): bit i set = contact row i is in the active set the derivative is taken through
+// (lam_i W_ii > kContactActiveTol) -- diagnostics / tests only.
 template <class M, typename T, bool WITH_A>
-IRS_HD void irs_contact_step_grad(const ModelParams& p, const T* x_ext, const T* u, T* xn_ext, T* Bext, T* Aext) {
+IRS_HD void irs_contact_step_grad(const ModelParams& p, const T* x_ext, const T* u, T* xn_ext, T* Bext, T* Aext,
+                                  unsigned* active_mask = nullptr) {
     constexpr int NX = M::NX, NC = M::NC, NU = M::NU;
     T q[NX], qn[NX], b[NX], J[NC][NX], phi[NC], Dinv[NX], W[NC][NC], lam[NC];
     const int iters = M::template assemble<T>(p, x_ext, u, q, Dinv, b, J, phi);
     if constexpr (irs_contact_exact<M>::value) irs_contact_qp_dual_exact<T, NX, NC>(Dinv, b, J, phi, W, lam);
     else irs_contact_qp_dual<T, NX, NC>(Dinv, b, J, phi, iters, W, lam);
     irs_contact_qp_primal<T, NX, NC>(q, Dinv, b, J, lam, qn);
+    if (active_mask != nullptr) {
+        unsigned mk = 0u;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) mk |= (lam[i] * W[i][i] > T(kContactActiveTol)) ? (1u << i) : 0u;
+        *active_mask = mk;
+    }
 #pragma unroll
     for (int k = 0; k < NX; ++k) xn_ext[M::perm(k)] = qn[k];
     int act[NU];
@@ -925,5 +934,14 @@ struct BoxPushModel {
         irs_sincos(q[2], sn, cs);
         irs_hand_box_rows<S, T>(q, sn, cs, a, rh, mu, J, phi, 0);
         return (int)p.v[7];
+    }
+};
+
+// Box pushing with its step QP solved EXACTLY (2 rows), like PlanarHandExactModel.
+struct BoxPushExactModel : BoxPushModel {
+    static constexpr bool EXACT = true;
+    template <typename S>
+    IRS_HD static void step(const ModelParams& p, const S* x_ext, const S* u, S* xn_ext) {
+        irs_contact_step<BoxPushExactModel, S>(p, x_ext, u, xn_ext);
     }
 };

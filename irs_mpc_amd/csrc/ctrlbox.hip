@@ -117,6 +117,12 @@ __global__ __launch_bounds__(64) void ctrlbox_descent_kernel(BoxArgs a) {
         return 0.0;
     };
     // ---- setup ------------------------------------------------------------------------
+    // sentinels: a launch that does not reach its epilogue must not leave a previous launch's values
+    // behind (info = -1 is rejected by the host like any other failure; cost = NaN)
+    if (lane == 0) {
+        a.info[0] = -1; a.info[1] = -1; a.info[2] = -1;
+        if (a.cost) a.cost[0] = __builtin_nan("");
+    }
     for (int q = lane; q < NR * NR; q += 64) {
         int i = q / NR, j = q % NR;
         Qsym[q] = 0.5 * (a.Q[i * NR + j] + a.Q[j * NR + i]);

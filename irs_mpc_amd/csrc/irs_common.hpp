@@ -38,6 +38,7 @@ void irs_set_error(const char* fmt, ...);
         case IRS_MODEL_BOX_PUSH: { using Model = BoxPushModel; __VA_ARGS__; } break; \
         case IRS_MODEL_PLANAR_HAND_EXACT: { using Model = PlanarHandExactModel; __VA_ARGS__; } break; \
         case IRS_MODEL_BOX_PIVOT_EXACT: { using Model = BoxPivotExactModel; __VA_ARGS__; } break; \
+        case IRS_MODEL_BOX_PUSH_EXACT: { using Model = BoxPushExactModel; __VA_ARGS__; } break; \
         default:                                                                  \
             irs_set_error("%s: unknown model id %d", __func__, (int)(model_id));  \
             return IRS_ERR_UNSUPPORTED;                                           \
@@ -56,6 +57,7 @@ static inline int irs_load_params(int model, const double* params, int n_params,
         case IRS_MODEL_BOX_PUSH: need = BoxPushModel::NPARAMS; break;
         case IRS_MODEL_PLANAR_HAND_EXACT: need = PlanarHandExactModel::NPARAMS; break;
         case IRS_MODEL_BOX_PIVOT_EXACT: need = BoxPivotExactModel::NPARAMS; break;
+        case IRS_MODEL_BOX_PUSH_EXACT: need = BoxPushExactModel::NPARAMS; break;
         default: irs_set_error("unknown model id %d", model); return IRS_ERR_UNSUPPORTED;
     }
     if (params == nullptr || n_params != need) {

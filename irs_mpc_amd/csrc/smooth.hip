@@ -373,6 +373,18 @@ __device__ __forceinline__ void finalize_timestep(const ModelParams& p, const do
         for (int j = 0; j < m; ++j) c -= L.AB[lane][n + j] * u[j];
         ct[(size_t)t * n + lane] = c;
     }
+    // Non-finite statistics (an f32 sample that diverged): tested on the BIT PATTERN -- this translation
+    // unit is built with -ffinite-math-only, under which `!(d > eps)` may be lowered to an ordered compare
+    // that a NaN passes.  info = P + 1 marks it (the pivot codes are 1..NZ).
+    {
+        bool nonfinite = false;
+        for (int q = lane; q < TR::P; q += 64) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(S[q]);
+            nonfinite = nonfinite || ((bits & 0x7ff0000000000000ull) == 0x7ff0000000000000ull);
+        }
+        if (__any(nonfinite) && lane == 0) L.bad = TR::P + 1;
+    }
+    wave_sync();
     if (lane == 0) info[t] = L.bad;
 }
 
@@ -811,6 +823,7 @@ bool is_light(int model, int mode) {
         case IRS_MODEL_BOX_PUSH: return light_m<BoxPushModel>(mode);
         case IRS_MODEL_PLANAR_HAND_EXACT: return light_m<PlanarHandExactModel>(mode);
         case IRS_MODEL_BOX_PIVOT_EXACT: return light_m<BoxPivotExactModel>(mode);
+        case IRS_MODEL_BOX_PUSH_EXACT: return light_m<BoxPushExactModel>(mode);
     }
     return false;
 }

@@ -72,6 +72,18 @@ class DeviceModel:
                                              B, _ptr(J, F64), _stream()), "irs_jacobian_xu_batch")
         return J
 
+    def contact_samples_f32(self, x, u, du):
+        """Per-sample f32 lanes of the FIRST_ORDER sample pass of a contact model (irs_contact_samples_f32):
+        x (n), u (m) f64, du (B,m) f32 -> Xn (B,n) f32, Bs (B,n,m) f32, active_mask (B) i32."""
+        B = du.shape[0]
+        Xn = torch.empty((B, self.n), dtype=F32, device=du.device)
+        Bs = torch.empty((B, self.n, self.m), dtype=F32, device=du.device)
+        mask = torch.empty((B,), dtype=torch.int32, device=du.device)
+        check(self.lib.irs_contact_samples_f32(self.model_id, self._p, self._np, _ptr(x, F64), _ptr(u, F64),
+                                               _ptr(du, F32), B, _ptr(Xn, F32), _ptr(Bs, F32), mask.data_ptr(),
+                                               _stream()), "irs_contact_samples_f32")
+        return Xn, Bs, mask
+
     def rollout_cost(self, x0, u_trj, Q, R, xd_trj):
         T = u_trj.shape[0]
         x_trj = torch.empty((T + 1, self.n), dtype=F64, device=u_trj.device)

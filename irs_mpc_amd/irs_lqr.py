@@ -134,50 +134,73 @@ class IrsLqr:
 
     def _local_descent_dev(self, x_trj, u_trj):
         At, Bt, ct = self._get_TV_matrices_dev(x_trj, u_trj)
-        box = self._box_bounds()
-        if box is not None and self._dm.box_descent_supported(self.T):
-            # genuine bounds (tv_lqr.py:112-123): T warm-started tail QPs, one launch
-            o = self._dm.tvlqr_box_descent(At, Bt, ct, self._Q, self._Qd, self._R, self._xd,
-                                           x_trj[0].contiguous(), *box, alpha_R=0.5,
-                                           rho=getattr(self.params, "qp_rho", 10.0),
-                                           max_iter=getattr(self.params, "qp_max_iter", 5000),
-                                           eps=getattr(self.params, "qp_eps", 1e-8))
-            cost = dev.evaluate_cost(o["x_new"], o["u_new"], self._Q, self._R, self._xd)
-            self._last = dict(At=At, Bt=Bt, ct=ct, K=None, k=None, info=o["info"][:1], box_info=o["info"])
-            self._box_used = True
-            return o["x_new"], o["u_new"], cost
-        # T MPC re-solves of the tail QP == one Riccati pass + closed-loop rollout
-        # while the box bounds are inactive (checked in iterate()); one launch.
-        self._box_used = False
+        # T MPC re-solves of the tail QP == one Riccati pass + closed-loop rollout while no box bound is
+        # active in ANY tail's plan; one launch.
         o = self._dm.tvlqr_descent(At, Bt, ct, self._Q, self._Qd, self._R, self._xd, x_trj[0].contiguous(),
                                    alpha_R=0.5)
         self._last = dict(At=At, Bt=Bt, ct=ct, K=o["K"], k=o["k"], info=o["info"])
-        return o["x_new"], o["u_new"], o["cost"]
-
-    # |bound| >= this is how the reference's scripts spell "no bound" (1e4, 1e5)
-    NO_BOUND = 1e3
+        self._box_used = False
+        box = self._box_bounds()
+        if box is None or self._tail_plans_within_bounds(At, Bt, ct, o["K"], o["k"], o["x_new"]):
+            return o["x_new"], o["u_new"], o["cost"]
+        if not self._dm.box_descent_supported(self.T):
+            raise NotImplementedError(
+                "a box bound is active and horizon T=%d does not fit the LDS-resident factorisation of the "
+                "bounded TV-LQR kernel (tv_lqr.py:112-123)" % self.T)
+        # genuine bounds (tv_lqr.py:112-123): T warm-started tail QPs, one launch
+        ob = self._dm.tvlqr_box_descent(At, Bt, ct, self._Q, self._Qd, self._R, self._xd,
+                                        x_trj[0].contiguous(), *box, alpha_R=0.5,
+                                        rho=getattr(self.params, "qp_rho", 10.0),
+                                        max_iter=getattr(self.params, "qp_max_iter", 5000),
+                                        eps=getattr(self.params, "qp_eps", 1e-8))
+        cost = dev.evaluate_cost(ob["x_new"], ob["u_new"], self._Q, self._R, self._xd)
+        self._last = dict(At=At, Bt=Bt, ct=ct, K=None, k=None, info=ob["info"][:1], box_info=ob["info"])
+        self._box_used = True
+        return ob["x_new"], ob["u_new"], cost
 
     def _box_bounds(self):
-        """(xlo, xhi, ulo, uhi) device vectors with +-inf for absent / 'no bound' entries, or
-        None when nothing is genuinely bounded."""
+        """(xlo, xhi, ulo, uhi) device vectors (+-inf where a component is unbounded), or None when
+        `xbound` and `ubound` are absent or infinite throughout.  Every FINITE entry is a genuine bound --
+        also the 1e4 / 1e5 the reference's scripts use to say "none": those simply never become active."""
         if getattr(self, "_box_cache", None) is not None:
             return self._box_cache if self._box_cache != () else None
 
         def vec(b, dim):
-            lo, hi = np.full(dim, -np.inf), np.full(dim, np.inf)
-            if b is not None:
-                bl, bh = np.asarray(b[0], float), np.asarray(b[1], float)
-                lo = np.where(np.abs(bl) < self.NO_BOUND, bl, -np.inf)
-                hi = np.where(np.abs(bh) < self.NO_BOUND, bh, np.inf)
-            return lo, hi
+            if b is None:
+                return np.full(dim, -np.inf), np.full(dim, np.inf)
+            return (np.broadcast_to(np.asarray(b[0], float), (dim,)).copy(),
+                    np.broadcast_to(np.asarray(b[1], float), (dim,)).copy())
 
         xlo, xhi = vec(self.xbound, self.dim_x)
         ulo, uhi = vec(self.ubound, self.dim_u)
-        if not (np.isfinite(xlo).any() or np.isfinite(xhi).any() or np.isfinite(ulo).any() or np.isfinite(uhi).any()):
+        self._box_host = (xlo, xhi, ulo, uhi)
+        if not any(np.isfinite(v).any() for v in self._box_host):
             self._box_cache = ()
             return None
-        self._box_cache = tuple(dev.to_dev(a) for a in (xlo, xhi, ulo, uhi))
+        self._box_cache = tuple(dev.to_dev(a) for a in self._box_host)
         return self._box_cache
+
+    def _tail_plans_within_bounds(self, At, Bt, ct, K, k, x_new):
+        """True iff the unconstrained solution of EVERY tail QP (start t, realised state x_t) respects the
+        box: then it is the solution of the bounded QP too (tv_lqr.py:112-123) and the Riccati descent above is
+        exact.  By Bellman the unconstrained plan of tail t is the policy (K_s, k_s), s >= t, rolled out on
+        the LINEAR model from x_t; all T plans advance together, one batched step per time index."""
+        xlo, xhi, ulo, uhi = self._box_host
+        A, B, c = At.cpu().numpy(), Bt.cpu().numpy(), ct.cpu().numpy()
+        Kh, kh, xs = K.cpu().numpy(), k.cpu().numpy(), x_new.cpu().numpy()
+        T = self.T
+        X = np.zeros((T, self.dim_x))
+        for s in range(T):
+            X[s] = xs[s]                                    # tail s starts from the realised state (x_0 of a
+            Xa = X[:s + 1]                                  # tail is data, not a decision variable)
+            U = Xa @ Kh[s].T + kh[s]
+            if (U < ulo).any() or (U > uhi).any():
+                return False
+            Xa = Xa @ A[s].T + U @ B[s].T + c[s]
+            if (Xa < xlo).any() or (Xa > xhi).any():
+                return False
+            X[:s + 1] = Xa
+        return True
 
     def _check_smooth_info(self):
         info = getattr(self, "_smooth_info", None)
@@ -186,26 +209,11 @@ class IrsLqr:
             raise ValueError("randomized-smoothing least squares is rank deficient at t=%d "
                              "(Gram matrix not positive definite; need more samples or a non-zero std)" % t)
 
-    def _check_bounds_inactive(self, x_new, u_new):
-        if getattr(self, "_box_used", False):
-            # the bounded QPs were solved; like OSQP hitting its iteration limit
-            # (tv_lqr.py:139-140), an unconverged tail problem is a failure
-            if int(self._last["box_info"][2].item()) != 0:
-                raise ValueError("TV_LQR failed. Optimization problem is not solved.")
-            return
-        tol = 1e-9
-        if self.xbound is not None:
-            lo, hi = np.asarray(self.xbound[0], float), np.asarray(self.xbound[1], float)
-            if (x_new < lo - tol).any() or (x_new > hi + tol).any():
-                raise NotImplementedError(
-                    "state bounds became active: the box-constrained TV-LQR of tv_lqr.py:112-123 "
-                    "is not implemented on device yet")
-        if self.ubound is not None:
-            lo, hi = np.asarray(self.ubound[0], float), np.asarray(self.ubound[1], float)
-            if (u_new < lo - tol).any() or (u_new > hi + tol).any():
-                raise NotImplementedError(
-                    "input bounds became active: the box-constrained TV-LQR of tv_lqr.py:112-123 "
-                    "is not implemented on device yet")
+    def _check_box_solved(self):
+        """Like OSQP hitting its iteration limit (tv_lqr.py:139-140): an unconverged bounded tail QP is a
+        failure."""
+        if getattr(self, "_box_used", False) and int(self._last["box_info"][2].item()) != 0:
+            raise ValueError("TV_LQR failed. Optimization problem is not solved.")
 
     # ---- irs_lqr/irs_lqr.py:188-218 ----------------------------------------
     def iterate(self, max_iterations):
@@ -222,7 +230,7 @@ class IrsLqr:
             if int(self._last["info"].item()) != 0:
                 raise ValueError("TV_LQR failed. Optimization problem is not solved.")
             self._check_smooth_info()
-            self._check_bounds_inactive(x_trj_new, u_trj_new)
+            self._check_box_solved()
 
             if self.verbose:
                 print("Iteration: {:02d} ".format(self.iter) + " || " +

@@ -2,7 +2,7 @@
 import numpy as np
 
 from ._lib import (MODEL_BICYCLE, MODEL_BOX_ON_BOX, MODEL_BOX_PIVOT, MODEL_BOX_PUSH, MODEL_PENDULUM,
-                   MODEL_BOX_PIVOT_EXACT, MODEL_PLANAR_HAND, MODEL_PLANAR_HAND_EXACT,
+                   MODEL_BOX_PIVOT_EXACT, MODEL_BOX_PUSH_EXACT, MODEL_PLANAR_HAND, MODEL_PLANAR_HAND_EXACT,
                    MODEL_QUADROTOR, MODEL_THREE_CART)
 from .dynamical_system import DynamicalSystem
 
@@ -135,13 +135,14 @@ class PlanarHandDynamics(QuasistaticDeviceDynamics):
     2-link arms, x = [xo, ql1, qr1, yo, ql2, qr2, th] (the reference's order), u = commanded joint
     angles [ql1, ql2, qr1, qr2].  Steps the
     Anitescu convex quasi-dynamic QP on the device (csrc/contact_models.hpp); the reference steps
-    the external quasistatic_simulator, so parity for this model is UNPINNED."""
+    the external quasistatic_simulator, so parity for this model is UNPINNED (DESIGN.md 3)."""
     device_model = MODEL_PLANAR_HAND
 
-    def __init__(self, h, mass=1.0, mu=0.5, pgs_iters=50, contact_solver="pgs"):
-        """contact_solver: "pgs" = `pgs_iters` over-relaxed projected sweeps on the step QP's dual (fast,
-        approximate when many contacts load the disc: DESIGN.md 7); "exact" = the dual active-set method
-        (what the reference's simulator does with Gurobi; 1.4x the time of the default, exact on every sample)."""
+    def __init__(self, h, mass=1.0, mu=0.5, pgs_iters=50, contact_solver="exact"):
+        """contact_solver: "exact" (default) = the step QP solved exactly by the dual active-set method -- what
+        the reference's simulator does (it hands every step QP to Gurobi, quasistatic_dynamics.py:146-164);
+        "pgs" = `pgs_iters` over-relaxed projected sweeps + an active-set polish (opt-in: 0.7x the time,
+        approximate on the few per cent of samples where many contacts load the disc)."""
         super().__init__()
         if contact_solver not in ("pgs", "exact"):
             raise ValueError("contact_solver must be 'pgs' or 'exact'")
@@ -182,14 +183,15 @@ class BoxPivotingDynamics(QuasistaticDeviceDynamics):
     u = commanded hand position.  Same contact scheme as the planar hand; parity UNPINNED."""
     device_model = MODEL_BOX_PIVOT
 
-    def __init__(self, h, mass=1.0, mu=0.5, pgs_iters=50, contact_solver="pgs"):
+    EXACT_MODEL = MODEL_BOX_PIVOT_EXACT
+
+    def __init__(self, h, mass=1.0, mu=0.5, pgs_iters=50, contact_solver="exact"):
+        """contact_solver: as for PlanarHandDynamics ("exact" = the reference's semantics, default)."""
         super().__init__()
         if contact_solver not in ("pgs", "exact"):
             raise ValueError("contact_solver must be 'pgs' or 'exact'")
         if contact_solver == "exact":
-            if type(self).device_model != MODEL_BOX_PIVOT:
-                raise NotImplementedError("contact_solver='exact' is built for box_pivoting and planar_hand")
-            self.device_model = MODEL_BOX_PIVOT_EXACT
+            self.device_model = type(self).EXACT_MODEL
         self.contact_solver = contact_solver
         self.h = h
         self.dim_x = 5
@@ -236,9 +238,9 @@ class BoxPushingDynamics(BoxPivotingDynamics):
     ships (examples/box_pushing/analysis/{xu,dxdu}_quasistatic.npy); the step reproduces the recorded
     trajectory to 3e-8 and `jacobian_xu` the recorded Jacobians to 5e-7."""
     device_model = MODEL_BOX_PUSH
+    EXACT_MODEL = MODEL_BOX_PUSH_EXACT
 
-    def __init__(self, h=0.1, mass=5.0, inertia=1.0 / 6.0, mu=0.5, pgs_iters=50, contact_solver="pgs"):
-        # (two contact rows: the sweeps + polish are exact here; no separate exact functor)
+    def __init__(self, h=0.1, mass=5.0, inertia=1.0 / 6.0, mu=0.5, pgs_iters=50, contact_solver="exact"):
         super().__init__(h, mass, mu, pgs_iters, contact_solver)
         self.g = 0.0             # box_pushing_setup.py:18
         self.inertia = inertia

@@ -24,9 +24,10 @@ Quasistatic part -- the contact STEP and its DERIVATIVE (jacobian_xu: the simula
 Dq_nextDqa_cmd, i.e. gradient modes "exact" / "first_order") are PINNED by simulator data the reference
 ships (examples/box_pushing/analysis/{xu,dxdu}_quasistatic.npy -> BoxPushOracle: the 80-step trajectory to
 3e-8, all 80 Jacobians to 5e-7 but the contact-onset one) and by the closed form of its 1-D case
-(box_on_box.py:11-20 -> BoxOnBoxOracle).  The step QP's dual is solved by over-relaxed projected sweeps +
-an active-set polish (what the device runs by default) or exactly (pgs_iters = 0: dual active-set method,
-certified against the QP's KKT conditions).
+(box_on_box.py:11-20 -> BoxOnBoxOracle).  The step QP's dual is solved EXACTLY by default (pgs_iters = 0: dual
+active-set method, certified against the QP's KKT conditions -- the reference's simulator hands every step
+QP to Gurobi, quasistatic_dynamics.py:146-164; the device default, contact_solver="exact"), or, opt-in, by
+`pgs_iters` over-relaxed projected sweeps + an active-set polish (the device's contact_solver="pgs").
 PARITY UNPINNED for the planar-hand / box-pivoting geometry and parameters (PlanarHandOracle,
 BoxPivotOracle) and for the *_quasistatic / ctrlbox_* functions: the reference steps pangtao22/quasistatic_simulator (external, not vendored, model
 files absent; plus Drake and Gurobi), so the contact step restates the published scheme
@@ -513,6 +514,13 @@ class _ContactQPOracle:
     def jacobian_xu(self, x, u):
         return self.jacobian_xu_batch(x[None], u[None])[0]
 
+    def active_mask_batch(self, x, u):
+        """Bit i set = contact row i is in the active set `jacobian_xu_batch` differentiates through
+        (lam_i W_ii > ACTIVE_TOL); the device's per-sample view is irs_contact_samples_f32."""
+        _, _, _, W, lam = self._pgs(np.atleast_2d(x), np.atleast_2d(u))
+        act = lam * np.einsum("bii->bi", W) > self.ACTIVE_TOL
+        return (act * (1 << np.arange(act.shape[1]))).sum(1).astype(np.int64)
+
 
 class BoxOnBoxOracle(_ContactQPOracle):
     """The reference's own 1-D instance of the quasi-dynamic step, examples/box_pushing/analysis/
@@ -562,7 +570,7 @@ class PlanarHandOracle(_ContactQPOracle):
     `dynamics_exact` solves the same QP to optimality (active-set via NNLS) as the physics check.
     """
 
-    def __init__(self, h, mass=1.0, mu=0.5, pgs_iters=50):
+    def __init__(self, h, mass=1.0, mu=0.5, pgs_iters=0):
         self.h = h
         self.dim_x, self.dim_u = 7, 4
         self.g = 10.0            # planar_hand_setup.py:23
@@ -657,7 +665,7 @@ class BoxPivotOracle(_ContactQPOracle):
 
     ground = True            # contacts with the ground y = 0 (and gravity) present
 
-    def __init__(self, h, mass=1.0, mu=0.5, pgs_iters=50):
+    def __init__(self, h, mass=1.0, mu=0.5, pgs_iters=0):
         self.h = h
         self.dim_x, self.dim_u = 5, 2
         self.g = 9.81
@@ -744,7 +752,7 @@ class BoxPushOracle(BoxPivotOracle):
 
     ground = False
 
-    def __init__(self, h=0.1, mass=5.0, inertia=1.0 / 6.0, mu=0.5, pgs_iters=50):
+    def __init__(self, h=0.1, mass=5.0, inertia=1.0 / 6.0, mu=0.5, pgs_iters=0):
         super().__init__(h, mass, mu, pgs_iters)
         self.g = 0.0
         self.inertia = inertia

@@ -1,5 +1,6 @@
 """The CPU leg of bench.py (no GPU): the bounded oracle sample on one core and on a pool of worker
-processes -- the analogue of the reference's ZMQ workers (irs_lqr_quasistatic.py:245-263)."""
+processes -- the analogue of the reference's ZMQ workers (irs_lqr_quasistatic.py:245-263) -- and the
+roofline bookkeeping of the JSON line."""
 import os
 import sys
 
@@ -7,21 +8,34 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def test_cpu_baseline_single_core_and_pool():
+def test_cpu_baseline_single_core_and_pool(monkeypatch):
     import bench
+    monkeypatch.setattr(bench, "usable_cpus", lambda: 2)
     w = bench.Workload("planar_hand", T=6, mode=None, host_only=True)
-    out = bench.cpu_baseline(w, 300, seconds=0.5, pool_cores=2)
+    out = bench.cpu_baseline(w, 300, budget_s=2.0, reps=5)
     assert out["kind"] == "port" and out["cores"] == 1 and out["value"] > 0
-    assert "oracle.zero_order_B_decoupled" in out["sample"]
+    assert "oracle.zero_order_B_decoupled" in out["sample"] and "median of 5" in out["sample"]
     pool = out["pool"]
     assert "error" not in pool, pool
-    assert pool["cores"] == 2 and pool["value"] > 0
+    assert pool["cores"] == 2 and pool["value"] > 0 and "median of 5" in pool["sample"]
     # the first-order twin and the pendulum workload use their own oracle functions
     w1 = bench.Workload("planar_hand", T=4, mode="first_order", host_only=True)
-    part, Ns, what = bench._cpu_problem(w1, 50)
+    part, what = bench._cpu_problem(w1, 50)
     part(0, 4)
-    assert what == "oracle.first_order_B_decoupled" and Ns == 50
+    assert what == "oracle.first_order_B_decoupled"
     w2 = bench.Workload("pendulum", T=5, host_only=True)
-    part, Ns, what = bench._cpu_problem(w2, 64)
+    part, what = bench._cpu_problem(w2, 64)
     part(1, 4)
-    assert what == "oracle.zero_order_TV" and Ns == 64
+    assert what == "oracle.zero_order_TV"
+
+
+def test_flop_model_counts_per_sample_work_only():
+    """roofline.frac must follow from the printed formula: the hoisted contact geometry is not counted, the
+    exact solver's data-dependent steps are not counted (a lower bound, said so in the formula)."""
+    import bench
+    f_pgs, s_pgs = bench.contact_flops_per_sample("pgs", 50, False)
+    assert f_pgs == 64 + 50 * 152 + 470 + 126 + 76 and "1500" not in s_pgs
+    f_ex, s_ex = bench.contact_flops_per_sample("exact", 50, False)
+    assert f_ex == 64 + 32 * 152 + 316 + 128 + 126 + 76 and "lower bound" in s_ex
+    f1, _ = bench.contact_flops_per_sample("exact", 50, True)
+    assert f1 - f_ex == 1208 - 76

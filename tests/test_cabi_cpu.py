@@ -77,7 +77,7 @@ def test_argument_validation_without_gpu(lib):
     assert 0 < lib.irs_quasistatic_box_lds_bytes(5, 120, 2) <= 160 * 1024 - 512   # box pivoting: its script's horizon fits
     assert lib.irs_smooth_finalize_ws(4, ph, 12, 2, 50, 100, one, one, one, one, one, one, one, one, 64, None) == -1
     assert lib.irs_cem_rollout_costs_quasistatic(4, ph, 12, 10, 0, one, one, one, one, one, one, one, None) == -1
-    assert lib.irs_model_info(10, None, None, None) != 0                     # ids 0..9 are registered
+    assert lib.irs_model_info(11, None, None, None) != 0                     # ids 0..10 are registered
 
 
 def test_product_does_not_import_oracle():

@@ -804,6 +804,50 @@ def test_planar_hand_first_order_decoupled_vs_oracle(amd):
     assert np.abs(o2["Bt"].cpu().numpy() - Bt).max() < 0.1
 
 
+@pytest.mark.parametrize("system,std", [("planar_hand", 0.3), ("planar_hand", 0.05), ("box_pivoting", 0.05)])
+def test_first_order_contact_per_sample_classification(amd, system, std):
+    """First-order smoothing of a contact model, sample by sample (irs_contact_samples_f32 = the f32 lanes of
+    the sample pass; quasistatic_dynamics.py:193-208): against the f64 oracle on the SAME f32-rounded inputs,
+      * the samples whose derivative block differs by more than 1e-3 -- an f32 lane and the f64 oracle on
+        different faces of the piecewise-linear step, i.e. a different active set -- are < 1 % of the draw,
+      * all other samples agree to f32 accuracy one by one, and their mean to the stated tolerance
+        (rtol 1e-4, atol 2e-5) -- so the sample pass's error is the flipped share times O(1), nothing else,
+      * every large deviation comes with a differing active-set mask (masks may differ WITHOUT consequence:
+        when contact rows are dependent -- a box resting on four corners -- the multipliers are not unique,
+        and the projector the derivative uses does not depend on which rows carry them)."""
+    from irs_mpc_amd import device as dev
+    N = 20000
+    if system == "planar_hand":
+        sys_d, sys_o = amd.PlanarHandDynamics(0.1), orc.PlanarHandOracle(0.1)
+        x0 = HAND.pack([0.0, 0.35, 0.0], [-np.pi / 4, -np.pi / 4], [np.pi / 4, np.pi / 4])
+        x = orc.rollout(sys_o, x0, np.tile(x0[HAND_IDX], (25, 1)))[-1]       # the settled grasp
+    else:
+        sys_d, sys_o = amd.BoxPivotingDynamics(0.1), orc.BoxPivotOracle(0.1)
+        x = orc.BoxPivotOracle.pack([0.0, 0.5, 0.0], [-0.6, 0.3])
+    idx = sys_o.indices_u_into_x
+    u = x[idx].copy()
+    n, m = sys_o.dim_x, sys_o.dim_u
+    du = (std * np.random.default_rng(5).normal(size=(N, m))).astype(np.float32)
+    Xn, Bs, mask = sys_d.dm().contact_samples_f32(dev.to_dev(x), dev.to_dev(u), dev.to_dev(du, dev.F32))
+    Xn, Bs, mask = Xn.cpu().numpy().astype(float), Bs.cpu().numpy().astype(float), mask.cpu().numpy()
+    X = np.tile(x.astype(np.float32).astype(float), (N, 1))
+    U = (u.astype(np.float32)[None] + du).astype(float)
+    Bo = sys_o.jacobian_xu_batch(X, U)[:, :, n:]
+    eB = np.abs(Bs - Bo).reshape(N, -1).max(1)
+    flipped = eB > 1e-3
+    assert flipped.mean() < 0.01, flipped.mean()
+    assert eB[~flipped].max() < 5e-4, eB[~flipped].max()
+    np.testing.assert_allclose(Bs[~flipped].mean(0), Bo[~flipped].mean(0), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(Xn[~flipped], sys_o.dynamics_batch(X, U)[~flipped], rtol=0, atol=2e-5)
+    assert not (flipped & (mask == sys_o.active_mask_batch(X, U))).any()
+    # and the sample pass is the mean of exactly these lanes
+    from irs_mpc_amd._lib import SMOOTH_FIRST_ORDER
+    o = sys_d.dm().smooth(SMOOTH_FIRST_ORDER, dev.to_dev(np.stack([x, x])), dev.to_dev(u[None]), None,
+                          dev.to_dev(du[None], dev.F32))
+    free = np.setdiff1d(np.arange(n), idx)
+    np.testing.assert_allclose(o["Bt"].cpu().numpy()[0][free], Bs.mean(0)[free], rtol=0, atol=2e-6)
+
+
 def test_planar_hand_exact_contact_solver_vs_oracle(amd):
     """contact_solver="exact" (IRS_MODEL_PLANAR_HAND_EXACT): the device's dual active-set solve of the step QP
     == the oracle's (`pgs_iters = 0`) in f64 (dynamics, active-set Jacobian), and through the f32 sample
@@ -813,7 +857,7 @@ def test_planar_hand_exact_contact_solver_vs_oracle(amd):
     T, N = 6, 2000
     sys_o = orc.PlanarHandOracle(0.1, pgs_iters=0)
     sys_d = amd.PlanarHandDynamics(0.1, contact_solver="exact")
-    pgs_d = amd.PlanarHandDynamics(0.1)
+    pgs_d = amd.PlanarHandDynamics(0.1, contact_solver="pgs")
     x0 = HAND.pack([0.0, 0.35, 0.0], [-np.pi / 4, -np.pi / 4], [np.pi / 4, np.pi / 4])
     u_trj = np.tile(x0[HAND_IDX], (T, 1))
     x_trj = orc.rollout(sys_o, x0, u_trj)
@@ -894,8 +938,9 @@ def test_box_pivot_exact_solver_random_states(amd):
     Ao, Bo, co = orc.zero_order_B_decoupled(sys_o, x_trj, u_trj, du.astype(np.float64))
     np.testing.assert_allclose(o["Bt"].cpu().numpy(), Bo, rtol=0, atol=2e-3)     # Kp = 5e4: f32 steps of a stiff hand
     np.testing.assert_allclose(o["ct"].cpu().numpy(), co, rtol=0, atol=2e-3)
-    with pytest.raises(NotImplementedError):
-        amd.BoxPushingDynamics(0.1, contact_solver="exact")
+    # box pushing (2 rows): the exact functor exists too and is the default
+    assert amd.BoxPushingDynamics(0.1).contact_solver == "exact"
+    assert amd.BoxPushingDynamics(0.1).device_model != amd.BoxPushingDynamics(0.1, contact_solver="pgs").device_model
 
 
 def test_capture_step_replays_the_two_launch_smoothing_step(amd):
@@ -1304,7 +1349,8 @@ def test_box_pivot_quasistatic_iteration_vs_oracle(amd):
 
 
 @pytest.mark.parametrize("system,solver", [("planar_hand", "pgs"), ("planar_hand", "exact"),
-                                           ("box_pivoting", "pgs"), ("box_pivoting", "exact"), ("box_pushing", "pgs")])
+                                           ("box_pivoting", "pgs"), ("box_pivoting", "exact"), ("box_pushing", "pgs"),
+                                           ("box_pushing", "exact")])
 @pytest.mark.parametrize("T", [7, 16, 23])
 def test_quasistatic_descent_outputs_are_self_consistent(amd, system, solver, T):
     """Whatever the model, the contact solver and the parity of the horizon: the trajectory the active-set

@@ -10,25 +10,32 @@ import sys
 out_dir, tag = sys.argv[1], sys.argv[2]
 
 
+SIZES = {"PlanarHandExact": ("planar_hand_exact", 50, 10000), "PlanarHand": ("planar_hand", 50, 10000),
+         "BoxPivotExact": ("box_pivoting_exact", 80, 6250), "BoxPivot": ("box_pivoting", 80, 6250),
+         "Quadrotor": ("quadrotor", 50, 10000), "Pendulum": ("pendulum", 30, 10000)}
+
+
 def short(name):
     """Key of the benchmarked kernels: <workload>[_exact]_<mode>[_rng][_unfused]_T.._N.. (bench.py's roofline()
-    looks up the supplied-samples, fused variants; the device-RNG variants are the ones of the iLQR loop)."""
+    looks up the supplied-samples, fused variants; the device-RNG variants are the ones of the iLQR loop).
+    T and N are those of the profiled command (tools/profile_round.sh), not read from the trace."""
     import re
     m = re.search(r"smooth_kernel<(?:\(anonymous namespace\)::)?(\w+)[,;] (\d)[,;] (true|false)[,;] (true|false)", name)
     if m:
         model, mode, rng, fuse = m.group(1), int(m.group(2)), m.group(3) == "true", m.group(4) == "true"
         tag = {0: "zero", 1: "first", 2: "zeroB"}[mode] + ("_rng" if rng else "") + ("" if fuse else "_unfused")
-        if "PlanarHandExact" in model:
-            return "planar_hand_exact_%s_T50_N10000" % tag
-        if "PlanarHand" in model:
-            return "planar_hand_%s_T50_N10000" % tag
-        if "Pendulum" in model:
-            return "pendulum_%s_T30_N10000" % tag
+        for k in ("PlanarHandExact", "PlanarHand", "BoxPivotExact", "BoxPivot", "Quadrotor", "Pendulum"):
+            if k in model:
+                w, T, N = SIZES[k]
+                return "%s_%s_T%d_N%d" % (w, tag, T, N)
         return None
-    if "ctrlbox_descent_kernel" in name:
-        return "planar_hand_exact_ctrlbox_descent_T50" if "PlanarHandExact" in name else "planar_hand_ctrlbox_descent_T50"
+    if "ctrlbox" in name and "descent" in name:
+        for k in ("PlanarHandExact", "PlanarHand", "BoxPivotExact", "BoxPivot"):
+            if k in name:
+                return "%s_ctrlbox_descent_T%d" % (SIZES[k][0], SIZES[k][1])
+        return None
     if "descent_kernel" in name:
-        return "pendulum_descent_T30"
+        return "quadrotor_descent_T50" if "Quadrotor" in name else "pendulum_descent_T30"
     return None
 
 

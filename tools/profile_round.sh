@@ -1,24 +1,26 @@
 #!/bin/bash
-# Round profile of the DEFAULT bench.py run (planar_hand T=50 N=1e4 zero-order-B, its first-order
-# sub-report, the pendulum sub-report), run on the GPU box through gpurun.  Under gpurun_out/prof_$TAG:
-#   stats/           rocprofv3 --kernel-trace --stats of the whole default run
+# Round profile of bench.py, run on the GPU box through gpurun.  Under gpurun_out/prof_$TAG:
+#   stats/           rocprofv3 --kernel-trace --stats of the whole DEFAULT run (every sub-report)
 #   pmc_<COUNTER>/   one separate --pmc pass per counter and per workload (HBM bytes; VALU counters)
 # One workload per profiled process (a --pmc pass over ~50k dispatches in one process segfaulted inside
-# rocprofv3's dispatch interception in an earlier round).
-TAG=${1:-r01g}
+# rocprofv3's dispatch interception in an earlier round).  Afterwards, in the build container:
+#   tools/adopt_profile.sh $TAG     copies the summaries into profiles/ and stamps them with the commit
+TAG=${1:-r02a}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 200 --warmup 20 --no-cpu-baseline"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py $ARGS > $OUT/stats.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py $ARGS > $OUT/stats.log 2>&1
 echo "stats rc=$?"
 for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py $ARGS --no-secondary > $OUT/pmc_$C.log 2>&1
-  echo "pass $C (planar_hand zero-order-B) rc=$?"
+  echo "pass $C (planar_hand zero-order-B, exact step QP) rc=$?"
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py $ARGS --no-secondary --mode first_order > $OUT/pmc_${C}_first.log 2>&1
   echo "pass $C (planar_hand first-order) rc=$?"
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py --steps 2000 --warmup 200 --no-cpu-baseline --workload pendulum > $OUT/pmc_${C}_pendulum.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py $ARGS --no-secondary --contact-solver pgs > $OUT/pmc_${C}_pgs.log 2>&1
+  echo "pass $C (planar_hand zero-order-B, sweeps) rc=$?"
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-secondary --workload pendulum > $OUT/pmc_${C}_pendulum.log 2>&1
   echo "pass $C (pendulum) rc=$?"
 done
 cd $R
