@@ -297,8 +297,12 @@ size_t irs_tvlqr_box_lds_bytes(int model, int T);
  *   control-box form of the QP: needs x_lo == NULL and at most ONE of the u / du pairs (every
  *   example of the reference); the active set and the backward sweep are carried from tail to
  *   tail; eps = tolerance on bounds and multipliers, max_iter = cap on safeguard iterations per
- *   tail, rho/relax unused;
- *   0 = 2 where it applies and fits LDS, else 1.
+ *   tail, rho/relax unused; one wave, every quantity of all T steps in LDS (planar hand: T <= 52);
+ *   3 = the same method with every step riding in one 16 x 16 matrix-core tile of homogeneous
+ *   coordinates (csrc/ctrlbox_mfma.hip; models with n + 2 m + 1 <= 16 after padding: all contact
+ *   models here): ~7x faster, and no horizon limit -- per-step records stay in LDS when they fit and
+ *   otherwise live in the workspace of irs_quasistatic_box_descent_wsx;
+ *   0 = 3 where it applies (on chip, or a workspace was given), else 2 where it fits LDS, else 1.
  * cost (1) DEV (may be NULL); info (3): [0] t+1 of a non-PD Hessian, [1] most iterations any tail
  * needed, [2] number of tails that did not converge.                                          */
 int irs_quasistatic_box_descent(int model, const double *params, int n_params, int T,
@@ -328,6 +332,21 @@ int irs_quasistatic_box_descent_ws(int model, const double *params, int n_params
                                    double *x_new, double *u_new, double *cost, int *info,
                                    double *act_io, void *stream);
 size_t irs_quasistatic_box_lds_bytes(int model, int T, int solver);
+/* The same with a device workspace for horizons whose per-step records do not fit the 160 KB of LDS
+ * (solver 3 / 0): `workspace` DEV, at least irs_quasistatic_descent_workspace_bytes(model, T, solver)
+ * bytes (0 = none needed: pass NULL); uninitialised scratch, no state is kept in it between calls.  The
+ * reference has no horizon limit (irs_lqr_quasistatic.py:325-345).                                    */
+int irs_quasistatic_box_descent_wsx(int model, const double *params, int n_params, int T,
+                                    const double *At, const double *Bt, const double *ct,
+                                    const double *Q, const double *Qd, const double *R,
+                                    const double *xd_trj, const double *x0,
+                                    const double *x_lo, const double *x_hi,
+                                    const double *u_lo, const double *u_hi,
+                                    const double *du_lo, const double *du_hi,
+                                    int solver, double rho, double relax, int max_iter, double eps,
+                                    double *x_new, double *u_new, double *cost, int *info,
+                                    double *act_io, void *workspace, size_t workspace_bytes, void *stream);
+size_t irs_quasistatic_descent_workspace_bytes(int model, int T, int solver);
 
 /* ---- Cross-entropy-method baseline (irs_lqr/cem.py:151-184) -------------------- */
 

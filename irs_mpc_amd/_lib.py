@@ -107,6 +107,11 @@ SIGNATURES["irs_quasistatic_box_descent_ws"] = (c_int, [c_int, POINTER(c_double)
                                                         _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, c_int, c_double,
                                                         c_double, c_int, c_double, _dp, _dp, _dp, _dp, _dp, c_void_p])
 SIGNATURES["irs_quasistatic_box_lds_bytes"] = (c_size_t, [c_int, c_int, c_int])
+SIGNATURES["irs_quasistatic_box_descent_wsx"] = (c_int, [c_int, POINTER(c_double), c_int, c_int, _dp, _dp, _dp, _dp, _dp,
+                                                         _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, c_int, c_double,
+                                                         c_double, c_int, c_double, _dp, _dp, _dp, _dp, _dp, _dp,
+                                                         c_size_t, c_void_p])
+SIGNATURES["irs_quasistatic_descent_workspace_bytes"] = (c_size_t, [c_int, c_int, c_int])
 SIGNATURES["irs_smooth_run"] = (c_int, [POINTER(SmoothCall), c_void_p])
 SIGNATURES["irs_descent_run"] = (c_int, [POINTER(DescentCall), c_void_p])
 

@@ -461,6 +461,7 @@ size_t irs_tvlqr_box_lds_bytes(int model, int T) {
 size_t irs_quasistatic_box_lds_bytes(int model, int T, int solver) {
     if (T <= 0) return 0;
     if (solver == 2) return irs_ctrlbox_lds_bytes(model, T);
+    if (solver == 3) return irs_ctrlbox_mfma_lds_bytes(model, T);
     size_t r = 0;
     IRS_DISPATCH_MODEL(model, {
         if constexpr (has_u_into_x<Model>::value)
@@ -514,8 +515,28 @@ int irs_quasistatic_box_descent_ws(int model, const double* params, int n_params
                                    int solver, double rho, double relax, int max_iter, double eps,
                                    double* x_new, double* u_new, double* cost, int* info, double* act_io,
                                    void* stream) {
+    return irs_quasistatic_box_descent_wsx(model, params, n_params, T, At, Bt, ct, Q, Qd, R, xd_trj, x0, x_lo, x_hi,
+                                           u_lo, u_hi, du_lo, du_hi, solver, rho, relax, max_iter, eps, x_new,
+                                           u_new, cost, info, act_io, nullptr, 0, stream);
+}
+
+size_t irs_quasistatic_descent_workspace_bytes(int model, int T, int solver) {
+    if (T <= 0 || (solver != 0 && solver != 3)) return 0;
+    const size_t lds = irs_ctrlbox_mfma_lds_bytes(model, T);
+    return (lds == 0 || lds <= (size_t)(160 * 1024 - 512)) ? 0 : irs_ctrlbox_mfma_record_bytes(model, T);
+}
+
+int irs_quasistatic_box_descent_wsx(int model, const double* params, int n_params, int T, const double* At,
+                                    const double* Bt, const double* ct, const double* Q, const double* Qd,
+                                    const double* R, const double* xd_trj, const double* x0,
+                                    const double* x_lo, const double* x_hi, const double* u_lo,
+                                    const double* u_hi, const double* du_lo, const double* du_hi,
+                                    int solver, double rho, double relax, int max_iter, double eps,
+                                    double* x_new, double* u_new, double* cost, int* info, double* act_io,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
     IRS_CHECK_ARG(T > 0 && At && Bt && ct && Q && Qd && R && xd_trj && x0 && x_new && u_new && info, "bad argument");
-    IRS_CHECK_ARG(solver >= 0 && solver <= 2, "solver must be 0 (auto), 1 (ADMM) or 2 (active set)");
+    IRS_CHECK_ARG(solver >= 0 && solver <= 3,
+                  "solver must be 0 (auto), 1 (ADMM), 2 (active set, lanes) or 3 (active set, matrix-core tiles)");
     IRS_CHECK_ARG((x_lo == nullptr) == (x_hi == nullptr) && (u_lo == nullptr) == (u_hi == nullptr) &&
                   (du_lo == nullptr) == (du_hi == nullptr), "give both sides of a bound or neither");
     IRS_CHECK_ARG(rho > 0.0 && relax > 0.0 && relax < 2.0 && max_iter > 0 && eps > 0.0, "bad ADMM parameter");
@@ -532,15 +553,28 @@ int irs_quasistatic_box_descent_ws(int model, const double* params, int n_params
     a.alpha = 1.0;      // tv_lqr.py:107 adds du'R du as an expression: the full quadratic
     a.rho = rho; a.relax = relax; a.eps = eps; a.T = T; a.max_iter = max_iter;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // one control box (or none) and no state bounds: the exact active-set solver applies
+    // one control box (or none) and no state bounds: the exact active-set solvers apply
     const bool one_box = x_lo == nullptr && !(u_lo != nullptr && du_lo != nullptr);
-    if (solver == 2 && !one_box) {
-        irs_set_error("irs_quasistatic_box_descent: the active-set solver handles ONE of u / du bounds and no x bounds");
+    if ((solver == 2 || solver == 3) && !one_box) {
+        irs_set_error("irs_quasistatic_box_descent: the active-set solvers handle ONE of u / du bounds and no x bounds");
         return IRS_ERR_UNSUPPORTED;
     }
-    if (solver == 2 || (solver == 0 && one_box &&
-                        irs_ctrlbox_lds_bytes(model, T) <= (size_t)(160 * 1024 - 512))) {
-        rc = irs_ctrlbox_launch(model, a, du_lo != nullptr ? 1 : 0, st);
+    const size_t kLds = (size_t)(160 * 1024 - 512);
+    const int kind = du_lo != nullptr ? 1 : 0;
+    if (one_box && (solver == 3 || solver == 0)) {
+        // matrix-core tiles: records on chip when they fit, in the caller's workspace otherwise
+        const size_t lds = irs_ctrlbox_mfma_lds_bytes(model, T);
+        const bool fits = lds != 0 && (lds <= kLds ||
+                                       (workspace != nullptr && workspace_bytes >= irs_ctrlbox_mfma_record_bytes(model, T)));
+        if (solver == 3 || fits) {
+            rc = irs_ctrlbox_mfma_launch(model, a, kind, static_cast<double*>(workspace), workspace_bytes, st);
+            if (rc != IRS_OK) return rc;
+            IRS_CHECK_LAUNCH();
+            return IRS_OK;
+        }
+    }
+    if (solver == 2 || (solver == 0 && one_box && irs_ctrlbox_lds_bytes(model, T) <= kLds)) {
+        rc = irs_ctrlbox_launch(model, a, kind, st);
         if (rc != IRS_OK) return rc;
         IRS_CHECK_LAUNCH();
         return IRS_OK;

@@ -36,3 +36,10 @@ struct has_u_into_x<M, std::void_t<decltype(M::u_into_x(0))>> : std::true_type {
 // controlled or the horizon does not fit LDS.
 int irs_ctrlbox_launch(int model, const BoxArgs& a, int kind, hipStream_t st);
 size_t irs_ctrlbox_lds_bytes(int model, int T);
+
+// ctrlbox_mfma.hip: the same active-set method with every step riding in one 16 x 16 matrix-core tile.
+// record_bytes: size of the per-step records (0 = the model does not fit the tile); lds_bytes: LDS needed
+// to keep them on chip (beyond the CU's 160 KB the caller supplies `ws`, >= record_bytes, in HBM).
+size_t irs_ctrlbox_mfma_record_bytes(int model, int T);
+size_t irs_ctrlbox_mfma_lds_bytes(int model, int T);
+int irs_ctrlbox_mfma_launch(int model, const BoxArgs& a, int kind, double* ws, size_t ws_bytes, hipStream_t st);

@@ -1,0 +1,651 @@
+// Quasistatic descent with ONE control box on the matrix cores -- the fast form of ctrlbox.hip.
+//
+// Same problem, same active-set method (ctrlbox.hip has the derivation: IrsLqrQuasistatic.local_descent,
+// irs_lqr/irs_lqr_quasistatic.py:286-345, re-solving solve_tvlqr's tail QP, irs_lqr/tv_lqr.py:30-137, for
+// every t, as a control-box LQR in s = [x; w], w = u_{t-1}; primal-dual active-set iterations, then the
+// primal active-set method), same answers -- the solution of a strictly convex QP is unique.  What differs
+// is how one iteration is carried out.  Everything rides in ONE 16 x 16 tile of homogeneous coordinates
+//
+//     z = [s (NS); 1; (pad to NHP); nu (M)],   NHP + M <= 16
+//     F_t = [A~ | B~] (NH x 16),  A~ = [A_ c_; 0 1],  B~ = [B_; 0]          s~+ = F_t z
+//     L_t = stage cost as a quadratic form in z (Q~_t with the -Qs sd_t column, Ru, the cross term Nc)
+//
+// BACKWARD step (8 dependent v_mfma_f64_16x16x4_f64, no data movement between them):
+//     Theta = L_t + F' P~ F            the Q-function of step t                      (2 x KA MFMAs)
+//     K~ (M x NH): free rows -H_ff^-1 (Theta_f,s~ + H_fp b_p e_h'), pinned rows b_j e_h'   (masked LDL', lanes)
+//     D  = Theta + Theta[:, nu] K~     rows < NH: Z; rows of nu: Y = Theta_nu,s~ + H K~  (1 MFMA)
+//     P~ = Z + K~' Y = [I; K~]' Theta [I; K~]                                          (1 MFMA)
+// -- the policy-evaluation form, valid for any K~, so rounding in K~ costs second order only; Y's pinned
+// rows are the multiplier rows (mu_j = Y_j s~).  The C/D register layout of that instruction is its
+// B-operand layout and the A-operand layout of the transpose, so P~ (symmetric), F' and K~' feed the next
+// product as they stand (tvlqr.hip, riccati_backward_mfma, has the layout).
+// FORWARD step (3 dependent MFMAs): the closed loop A~cl = A~ + B~ K~ and the M output rows (K~_j for a free
+// component, Y_j for a pinned one) are stored as ONE 16 x NHP tile G_t, in A-operand register image;
+//     [s~_{t+1}; out] = G_t s~_t
+// yields the next state (rows < NH: already in B-operand layout for the next step) and the controls /
+// multipliers (rows NHP..) together.  The state never leaves the registers.
+//
+// Per-step records (G_t image, P~_t, active set, bounds, iterates) live in LDS when the horizon fits
+// (planar hand: T <= 55; box pivoting: T <= 200) and otherwise in a caller-supplied global workspace
+// (L2-resident; same code, slower) -- the reference has no horizon limit (irs_lqr_quasistatic.py:325-345).
+// f64 matrix and vector rates are equal on gfx950: what the tile buys is not flops but the absence of
+// LDS round trips and cross-lane traffic inside a step (ctrlbox.hip: 6 LDS phases, ~7000 cycles per
+// backward step; here ~1000).
+#include "boxqp.hpp"
+
+namespace {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+constexpr int kPdasIterM = 10;
+constexpr int KIND_ABS_M = 0, KIND_REL_M = 1;
+
+__device__ __forceinline__ double fast_rcp_m(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double readlane_d(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wmax_d(double v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v = fmax(v, __shfl_xor(v, s, 64));
+    return v;
+}
+__device__ __forceinline__ double wmin_d(double v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v = fmin(v, __shfl_xor(v, s, 64));
+    return v;
+}
+__device__ __forceinline__ int wmax_i(int v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v = max(v, __shfl_xor(v, s, 64));
+    return v;
+}
+__device__ __forceinline__ int wmin_i(int v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v = min(v, __shfl_xor(v, s, 64));
+    return v;
+}
+
+template <int NR, int M>
+struct MfLayout {
+    static constexpr int NS = NR + M, NH = NS + 1, NHP = (NH + 3) / 4 * 4, KA = NHP / 4;
+    static constexpr bool FITS = NHP + M <= 16 && M <= 4;
+    // doubles per time step: forward tile image, P~ image (lanes with col < NHP), 6 control vectors, Qs sd
+    static constexpr int GT = KA * 64, PT = KA * 4 * NHP;
+    static __host__ __device__ size_t oG(int) { return 0; }
+    static __host__ __device__ size_t oP(int T) { return (size_t)T * GT; }
+    static __host__ __device__ size_t oV(int T) { return oP(T) + (size_t)(T + 1) * PT; }       // 6 x (T, M)
+    static __host__ __device__ size_t oQ(int T) { return oV(T) + (size_t)6 * T * M; }          // (T+1, NR)
+    static __host__ __device__ size_t rec_doubles(int T) { return oQ(T) + (size_t)(T + 1) * NR; }
+    // always in LDS: Qsym, Qdsym (NR^2), Rsym (M^2), sstart (NH), slack
+    static constexpr int small = 2 * NR * NR + M * M + NH + 16;
+};
+
+// The f64 contact step needs hundreds of registers; out of line so that the solver's loops keep theirs.
+template <class Model>
+__device__ __noinline__ void true_step_m(const ModelParams& p, const double* x, const double* u, double* xn) {
+    Model::template step<double>(p, x, u, xn);
+}
+
+template <class Model, int KIND, bool LDSREC>
+__global__ __launch_bounds__(64) void ctrlbox_mfma_kernel(BoxArgs a, double* gws) {
+    constexpr int NR = Model::NX, M = Model::NU;
+    using L = MfLayout<NR, M>;
+    constexpr int NS = L::NS, NH = L::NH, NHP = L::NHP, KA = L::KA, RN = L::KA;   // RN: register of rows NHP..NHP+3
+    static_assert(L::FITS, "one 16 x 16 tile");
+    constexpr double INF = __builtin_huge_val();
+    extern __shared__ double lds[];
+    const int T = a.T, lane = threadIdx.x, col = lane & 15, rg = lane >> 4;
+
+    double* rec = LDSREC ? lds : gws;                       // per-step records
+    double* sm = LDSREC ? lds + L::rec_doubles(T) : lds;    // small tables, always LDS
+    double* Gt = rec + L::oG(T);
+    double* Pt = rec + L::oP(T);
+    double* Vv = rec + L::oV(T);
+    double* act_ = Vv;
+    double* lo_ = Vv + (size_t)T * M;
+    double* hi_ = Vv + (size_t)2 * T * M;
+    double* uu_ = Vv + (size_t)3 * T * M;
+    double* us_ = Vv + (size_t)4 * T * M;
+    double* mu_ = Vv + (size_t)5 * T * M;
+    double* qsd = rec + L::oQ(T);
+    double* Qsym = sm;
+    double* Qdsym = Qsym + NR * NR;
+    double* Rsym = Qdsym + NR * NR;
+    double* sstart = Rsym + M * M;                          // NH entries: s, then 1
+
+    // orders this wave's memory traffic on the records: LDS executes one wave's operations in issue order
+    // (compiler barrier only); global records additionally need the stores drained and this CU's L1 dropped
+    auto rsync = [&]() {
+        if constexpr (LDSREC) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // ---- setup ------------------------------------------------------------------------
+    if (lane == 0) {
+        a.info[0] = -1; a.info[1] = -1; a.info[2] = -1;     // sentinels: see ctrlbox.hip
+        if (a.cost) a.cost[0] = __builtin_nan("");
+    }
+    for (int q = lane; q < NR * NR; q += 64) {
+        const int i = q / NR, j = q % NR;
+        Qsym[q] = 0.5 * (a.Q[i * NR + j] + a.Q[j * NR + i]);
+        Qdsym[q] = 0.5 * (a.Qd[i * NR + j] + a.Qd[j * NR + i]);
+    }
+    for (int q = lane; q < M * M; q += 64) {
+        const int i = q / M, j = q % M;
+        Rsym[q] = 0.5 * (a.R[i * M + j] + a.R[j * M + i]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const double* blo = KIND == KIND_ABS_M ? a.ulo : a.dlo;
+    const double* bhi = KIND == KIND_ABS_M ? a.uhi : a.dhi;
+    const int bs = KIND == KIND_ABS_M ? a.su : a.sd;
+    for (int q = lane; q < T * M; q += 64) {
+        const double lo = blo ? blo[(size_t)(q / M) * bs + q % M] : -INF;
+        const double hi = bhi ? bhi[(size_t)(q / M) * bs + q % M] : INF;
+        lo_[q] = lo;
+        hi_[q] = hi;
+        // warm start of the first tail (the previous iLQR iteration's converged set), cleaned:
+        // {-1, 0, +1}, and nothing pinned at an infinite bound
+        double a0 = a.act_io ? a.act_io[q] : 0.0;
+        a0 = a0 < 0.0 ? (lo > -INF ? -1.0 : 0.0) : (a0 > 0.0 ? (hi < INF ? 1.0 : 0.0) : 0.0);
+        act_[q] = a0;
+        uu_[q] = 0.0; us_[q] = 0.0; mu_[q] = 0.0;
+    }
+    for (int q = lane; q < (T + 1) * NR; q += 64) {
+        const int t = q / NR, i = q % NR;
+        double s = 0.0;
+        for (int j = 0; j < NR; ++j) s += Qsym[i * NR + j] * a.xd[(size_t)t * NR + j];
+        qsd[q] = s;                                         // (Qs sd_t)[:NR]; the w block of sd is zero
+    }
+    for (size_t q = lane; q < (size_t)T * L::GT; q += 64) Gt[q] = 0.0;      // unwritten image entries stay zero
+    // stage-cost tile without its time-varying column, in C/D layout (row = rg + 4 r, col)
+    auto Ru = [&](int i, int j) { return Rsym[i * M + j]; };
+    v4d Lc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = rg + 4 * r;
+        double v = 0.0;
+        if (row < NR && col < NR) v = Qsym[row * NR + col];
+        else if (row >= NHP && row < NHP + M && col >= NHP && col < NHP + M) v = Ru(row - NHP, col - NHP);
+        if (KIND == KIND_ABS_M) {
+            // (u - w)'R(u - w): R on the w block, -R between w and u
+            if (row >= NR && row < NS && col >= NR && col < NS) v = Ru(row - NR, col - NR);
+            else if (row >= NR && row < NS && col >= NHP && col < NHP + M) v = -Ru(row - NR, col - NHP);
+            else if (col >= NR && col < NS && row >= NHP && row < NHP + M) v = -Ru(row - NHP, col - NR);
+        }
+        Lc[r] = v;
+    }
+    // terminal cost-to-go P~_T = [Qsd, -Qsd sd_T; ., 0], Qsd = diag(Qd, 0)
+    if (col < NHP) {
+#pragma unroll
+        for (int r = 0; r < KA; ++r) {
+            const int row = rg + 4 * r;
+            double v = 0.0;
+            if (row < NR && col < NR) v = Qdsym[row * NR + col];
+            else if ((col == NS && row < NR) || (row == NS && col < NR)) {
+                const int i = col == NS ? row : col;
+                for (int j = 0; j < NR; ++j) v -= Qdsym[i * NR + j] * a.xd[(size_t)T * NR + j];
+            }
+            Pt[(size_t)T * L::PT + (r * 4 + rg) * NHP + col] = v;
+        }
+    }
+    rsync();
+
+    // ---- step data straight from the caller's (A, B, c): F_t in C/D layout, B~ in A-operand layout ----
+    auto load_F = [&](int t, v4d& F, double& Ba) {
+        const double* At = a.At + (size_t)t * NR * NR;
+        const double* Bt = a.Bt + (size_t)t * NR * M;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rg + 4 * r;
+            double v = 0.0;
+            if (row < NR) {
+                if (col < NR) v = At[row * NR + col];
+                else if (col < NS) v = KIND == KIND_REL_M ? Bt[row * M + (col - NR)] : 0.0;
+                else if (col == NS) v = a.ct[(size_t)t * NR + row];
+                else if (col >= NHP && col < NHP + M) v = Bt[row * M + (col - NHP)];
+            } else if (row < NS) {
+                if (KIND == KIND_REL_M && col == row) v = 1.0;
+                else if (col == NHP + (row - NR)) v = 1.0;
+            } else if (row == NS && col == NS) {
+                v = 1.0;
+            }
+            F[r] = v;
+        }
+        // A-operand of B~: lane (i = col, k = rg) holds B~[i][k]
+        Ba = 0.0;
+        if (rg < M) {
+            if (col < NR) Ba = Bt[col * M + rg];
+            else if (col < NS) Ba = (col - NR) == rg ? 1.0 : 0.0;
+        }
+    };
+
+    int bad = 0;
+    // ---- backward sweep t = t_hi .. t_lo (descending): policies for the pinned sets, cost-to-go, tiles ----
+    auto backward_sweep = [&](int t_hi, int t_lo) {
+        if (t_hi < t_lo) return;
+        v4d P = {0.0, 0.0, 0.0, 0.0};
+        if (col < NHP) {
+#pragma unroll
+            for (int r = 0; r < KA; ++r) P[r] = Pt[(size_t)(t_hi + 1) * L::PT + (r * 4 + rg) * NHP + col];
+        }
+        v4d Fn;
+        double Ban;
+        load_F(t_hi, Fn, Ban);
+        for (int t = t_hi; t >= t_lo; --t) {
+            const v4d F = Fn;
+            const double Ba = Ban;
+            if (t > t_lo) load_F(t - 1, Fn, Ban);            // prefetch
+            // active set and pinned values of this step (wave-uniform reads)
+            double ac[M], bb[M];
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                ac[j] = act_[(size_t)t * M + j];
+                bb[j] = ac[j] < 0.0 ? lo_[(size_t)t * M + j] : hi_[(size_t)t * M + j];
+            }
+            v4d Lt = Lc;
+#pragma unroll
+            for (int r = 0; r < KA; ++r) {
+                const int row = rg + 4 * r;
+                if (col == NS && row < NR) Lt[r] = -qsd[(size_t)t * NR + row];
+                else if (row == NS && col < NR) Lt[r] = -qsd[(size_t)t * NR + col];
+            }
+            // D1 = P~ F ;  Theta = L_t + F' D1
+            v4d D1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < KA; ++s) D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[s], F[s], D1, 0, 0, 0);
+            v4d Th = Lt;
+#pragma unroll
+            for (int s = 0; s < KA; ++s) Th = __builtin_amdgcn_mfma_f64_16x16x4f64(F[s], D1[s], Th, 0, 0, 0);
+            // H = Theta_nu,nu to every lane; this lane's column of Theta_nu,: (rows NHP + i sit in register RN
+            // of lanes 16 i + col)
+            double H[M][M], gc[M];
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+#pragma unroll
+                for (int j = 0; j < M; ++j) H[i][j] = readlane_d(Th[RN], 16 * i + NHP + j);
+                gc[i] = __shfl(Th[RN], 16 * i + col, 64);
+            }
+            // masked system: free rows/columns of H, identity on the pinned ones
+            double Lm[M][M], Dg[M], Dinv[M], y[M];
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                const bool fj = ac[j] == 0.0;
+                double dj = fj ? H[j][j] : 1.0;
+#pragma unroll
+                for (int l = 0; l < j; ++l) dj -= Lm[j][l] * Lm[j][l] * Dg[l];
+                if (!(dj > 0.0) && bad == 0) bad = t + 1;
+                Dg[j] = dj;
+                Dinv[j] = fast_rcp_m(dj);
+#pragma unroll
+                for (int i = j + 1; i < M; ++i) {
+                    double s = (fj && ac[i] == 0.0) ? H[i][j] : 0.0;
+#pragma unroll
+                    for (int l = 0; l < j; ++l) s -= Lm[i][l] * Lm[j][l] * Dg[l];
+                    Lm[i][j] = s * Dinv[j];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                // right-hand side of the free rows: Theta_f,col + (homogeneous column) sum_p H_fp b_p
+                double s = 0.0;
+                if (ac[i] == 0.0) {
+                    s = gc[i];
+                    if (col == NS) {
+#pragma unroll
+                        for (int l = 0; l < M; ++l) s += ac[l] != 0.0 ? H[i][l] * bb[l] : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int l = 0; l < i; ++l) s -= Lm[i][l] * y[l];
+                y[i] = s;
+            }
+#pragma unroll
+            for (int i = M - 1; i >= 0; --i) {
+                double s = y[i] * Dinv[i];
+#pragma unroll
+                for (int l = i + 1; l < M; ++l) s -= Lm[l][i] * y[l];
+                y[i] = s;
+            }
+            // K~[rg][col] in B-operand layout (= K~' in A-operand layout)
+            double Kb = 0.0;
+            bool my_free = false;
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                const double kv = ac[i] == 0.0 ? -y[i] : (col == NS ? bb[i] : 0.0);
+                if (i == rg) { Kb = kv; my_free = ac[i] == 0.0; }
+            }
+            if (rg >= M || col >= NH) Kb = 0.0;
+            // D = Theta + Theta[:, nu] K~ ;  P~ = D + K~' Y, Y = rows of nu of D
+            v4d D = __builtin_amdgcn_mfma_f64_16x16x4f64(Th[RN], Kb, Th, 0, 0, 0);
+            v4d Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(Kb, D[RN], D, 0, 0, 0);
+            // closed loop A~cl = A~ + B~ K~ (off the chain of the next step)
+            v4d Acl = __builtin_amdgcn_mfma_f64_16x16x4f64(Ba, Kb, F, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rg + 4 * r;
+                P[r] = (r < KA && row < NH && col < NH) ? Pn[r] : 0.0;
+            }
+            // records: P~_t, and the forward tile G_t in A-operand register image -- element [i][k] at
+            // register k >> 2 of lane (k & 3) * 16 + i
+            if (col < NHP) {
+#pragma unroll
+                for (int r = 0; r < KA; ++r) Pt[(size_t)t * L::PT + (r * 4 + rg) * NHP + col] = P[r];
+            }
+            double* G = Gt + (size_t)t * L::GT;
+            if (col < NH) {
+#pragma unroll
+                for (int r = 0; r < KA; ++r) G[(col >> 2) * 64 + (col & 3) * 16 + (rg + 4 * r)] = Acl[r];
+                if (rg < M) G[(col >> 2) * 64 + (col & 3) * 16 + (NHP + rg)] = my_free ? Kb : D[RN];
+            }
+        }
+        rsync();
+    };
+
+    // ---- policy rollout on the linear model from sstart: controls -> `dst` (uu_ or us_), multipliers -> mu_ ----
+    auto policy_rollout = [&](int t0, double* dst) {
+        v4d S = {0.0, 0.0, 0.0, 0.0};
+        if (col == 0) {
+#pragma unroll
+            for (int s = 0; s < KA; ++s) {
+                const int k = rg + 4 * s;
+                S[s] = k < NH ? sstart[k] : 0.0;
+            }
+        }
+        double g[KA], gn[KA];
+        double acn = 0.0, bdn = 0.0;
+        auto fetch = [&](int t, double* gg, double& acx, double& bdx) {
+            const double* G = Gt + (size_t)t * L::GT;
+#pragma unroll
+            for (int s = 0; s < KA; ++s) gg[s] = G[s * 64 + lane];
+            const int j = rg < M ? rg : 0;
+            acx = act_[(size_t)t * M + j];
+            bdx = acx < 0.0 ? lo_[(size_t)t * M + j] : hi_[(size_t)t * M + j];
+        };
+        fetch(t0, gn, acn, bdn);
+        for (int t = t0; t < T; ++t) {
+#pragma unroll
+            for (int s = 0; s < KA; ++s) g[s] = gn[s];
+            const double acx = acn, bdx = bdn;
+            if (t + 1 < T) fetch(t + 1, gn, acn, bdn);
+            v4d Dn = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < KA; ++s) Dn = __builtin_amdgcn_mfma_f64_16x16x4f64(g[s], S[s], Dn, 0, 0, 0);
+            if (col == 0 && rg < M) {
+                const double o = Dn[RN];                       // K~_j s~ (free) or the multiplier Y_j s~ (pinned)
+                dst[(size_t)t * M + rg] = acx == 0.0 ? o : bdx;
+                mu_[(size_t)t * M + rg] = acx == 0.0 ? 0.0 : o;
+            }
+#pragma unroll
+            for (int s = 0; s < KA; ++s) S[s] = Dn[s];
+        }
+        rsync();
+    };
+
+    // ---- MPC loop --------------------------------------------------------------------
+    double xr[NR], ur[M], xn[NR], up[M];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) xr[i] = a.x0[i];
+#pragma unroll
+    for (int j = 0; j < M; ++j) up[j] = 0.0;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) a.x_new[i] = xr[i];
+    }
+    auto quad = [&](const double* Wq, const double* e, int Kd) -> double {
+        double s = 0.0;
+        for (int i = 0; i < Kd; ++i)
+            for (int j = 0; j < Kd; ++j) s += e[i] * Wq[i * Kd + j] * e[j];
+        return s;
+    };
+    double cost = 0.0;
+    int it_max = 0, n_fail = 0;
+    const double tol = a.eps;
+    bool full = true;                                  // no valid backward sweep yet
+
+    for (int tau = 0; tau < T; ++tau) {
+        // start state [x; x[idx]]: each tail's first du is measured from the realised actuated
+        // position (tv_lqr.py:99-100 at the tail's local t = 0)
+        double ub[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            double v = xr[0];
+#pragma unroll
+            for (int i = 1; i < NR; ++i) v = (i == Model::u_into_x(j)) ? xr[i] : v;
+            ub[j] = v;
+        }
+        if (lane < NH) {
+            double v = xr[0];
+#pragma unroll
+            for (int i = 1; i < NR; ++i) v = (i == lane) ? xr[i] : v;
+#pragma unroll
+            for (int j = 0; j < M; ++j) v = (NR + j == lane) ? ub[j] : v;
+            sstart[lane] = lane == NS ? 1.0 : v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const int t0 = tau;
+        int t_dirty = full ? T - 1 : t0 - 1;           // the sweep of the previous tail covers t >= tau
+        int iters = 0;
+        bool conv = false;
+        // ---- phase 1: primal-dual active set
+        for (int it = 0; it < kPdasIterM && !conv; ++it) {
+            ++iters;
+            backward_sweep(t_dirty, t0);
+            policy_rollout(t0, uu_);
+            int chg = -1;
+            for (int q = t0 * M + lane; q < T * M; q += 64) {
+                const double ac = act_[q], u = uu_[q], mu = mu_[q];
+                double nw = ac;
+                if (ac == 0.0) {
+                    if (u < lo_[q] - tol) nw = -1.0;
+                    else if (u > hi_[q] + tol) nw = 1.0;
+                } else if (ac < 0.0) {
+                    if (mu < -tol) nw = 0.0;
+                } else {
+                    if (mu > tol) nw = 0.0;
+                }
+                if (nw != ac) { act_[q] = nw; chg = max(chg, q / M); }
+            }
+            chg = wmax_i(chg);
+            rsync();
+            if (chg < 0) conv = true;
+            else t_dirty = chg;
+        }
+        // ---- phase 2: primal active set from the clipped iterate
+        if (!conv) {
+            int chg = -1;
+            for (int q = t0 * M + lane; q < T * M; q += 64) {
+                const double lo = lo_[q], hi = hi_[q];
+                const double u = fmin(fmax(uu_[q], lo), hi);
+                uu_[q] = u;
+                const double nw = u <= lo ? -1.0 : (u >= hi ? 1.0 : 0.0);
+                if (nw != act_[q]) { act_[q] = nw; chg = max(chg, q / M); }
+            }
+            chg = wmax_i(chg);
+            rsync();
+            t_dirty = max(t_dirty, chg);
+            for (int it2 = 0; it2 < a.max_iter && !conv; ++it2) {
+                ++iters;
+                backward_sweep(t_dirty, t0);
+                t_dirty = t0 - 1;
+                policy_rollout(t0, us_);
+                // largest feasible step along d = us - u over the free components
+                double best = INF;
+                int bq = 0x7fffffff;
+                for (int q = t0 * M + lane; q < T * M; q += 64) {
+                    if (act_[q] == 0.0) {
+                        const double u = uu_[q], d = us_[q] - u;
+                        double room = INF;
+                        if (d > 0.0) room = (hi_[q] - u) / d;
+                        else if (d < 0.0) room = (lo_[q] - u) / d;
+                        if (room < best) { best = room; bq = q; }
+                    }
+                }
+                const double alpha = wmin_d(best);
+                if (alpha < 1.0) {
+                    const int qb = wmin_i(best == alpha ? bq : 0x7fffffff);
+                    for (int q = t0 * M + lane; q < T * M; q += 64) {
+                        const double u = uu_[q], d = us_[q] - u;
+                        if (q == qb) {
+                            act_[q] = d > 0.0 ? 1.0 : -1.0;
+                            uu_[q] = d > 0.0 ? hi_[q] : lo_[q];
+                        } else {
+                            uu_[q] = u + alpha * d;
+                        }
+                    }
+                    rsync();
+                    t_dirty = qb / M;
+                    continue;
+                }
+                // full step: u = us; optimal if every pinned multiplier has the right sign
+                double worst = 0.0;
+                int wq = 0x7fffffff;
+                for (int q = t0 * M + lane; q < T * M; q += 64) {
+                    uu_[q] = us_[q];
+                    const double ac = act_[q], mu = mu_[q];
+                    const double viol = ac < 0.0 ? -mu : (ac > 0.0 ? mu : 0.0);
+                    if (viol > worst) { worst = viol; wq = q; }
+                }
+                const double wmax = wmax_d(worst);
+                if (wmax <= tol) {
+                    rsync();
+                    conv = true;
+                } else {
+                    const int qw = wmin_i(worst == wmax ? wq : 0x7fffffff);
+                    if (lane == 0) act_[qw] = 0.0;
+                    rsync();
+                    t_dirty = qw / M;
+                }
+            }
+        }
+        it_max = max(it_max, iters);
+        n_fail += conv ? 0 : 1;
+        full = !conv;
+        if (tau == 0 && a.act_io != nullptr) {
+            for (int q = lane; q < T * M; q += 64) a.act_io[q] = act_[q];
+        }
+        // first control of the tail solution (clipped), true dynamics step
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            const size_t q = (size_t)tau * M + j;
+            const double v = fmin(fmax(uu_[q], lo_[q]), hi_[q]);
+            ur[j] = KIND == KIND_ABS_M ? v : ub[j] + v;
+        }
+        {   // IrsLqrQuasistatic.eval_cost (irs_lqr_quasistatic.py:153-194)
+            double e[NR], dv[M];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) e[i] = xr[i] - a.xd[(size_t)tau * NR + i];
+#pragma unroll
+            for (int j = 0; j < M; ++j) dv[j] = ur[j] - (tau == 0 ? ub[j] : up[j]);
+            cost += quad(Qsym, e, NR) + quad(Rsym, dv, M);
+        }
+        true_step_m<Model>(a.p, xr, ur, xn);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) xr[i] = xn[i];
+#pragma unroll
+        for (int j = 0; j < M; ++j) up[j] = ur[j];
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < M; ++j) a.u_new[(size_t)tau * M + j] = ur[j];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) a.x_new[(size_t)(tau + 1) * NR + i] = xr[i];
+        }
+        rsync();
+    }
+    {
+        double e[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) e[i] = xr[i] - a.xd[(size_t)T * NR + i];
+        cost += quad(Qdsym, e, NR);
+    }
+    if (lane == 0) {
+        a.info[0] = bad; a.info[1] = it_max; a.info[2] = n_fail;
+        if (a.cost) a.cost[0] = cost;
+    }
+}
+
+constexpr size_t kLdsMax = 160 * 1024 - 512;
+
+template <class Model, int KIND>
+int launch_ctrlbox_mfma(const BoxArgs& a, double* ws, size_t ws_bytes, hipStream_t st) {
+    using L = MfLayout<Model::NX, Model::NU>;
+    const size_t rec = L::rec_doubles(a.T) * sizeof(double), small = L::small * sizeof(double);
+    const bool in_lds = rec + small <= kLdsMax;
+    if (!in_lds && (ws == nullptr || ws_bytes < rec)) {
+        irs_set_error("irs_quasistatic_box_descent: horizon T=%d needs a %zu-byte workspace for the matrix-core "
+                      "active-set solver (records do not fit LDS)", a.T, rec);
+        return IRS_ERR_UNSUPPORTED;
+    }
+    const size_t bytes = in_lds ? rec + small : small;
+    if (in_lds) {
+        auto kern = ctrlbox_mfma_kernel<Model, KIND, true>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) {
+            irs_set_error("irs_quasistatic_box_descent: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return IRS_ERR_HIP;
+        }
+        hipLaunchKernelGGL(kern, dim3(1), dim3(64), bytes, st, a, (double*)nullptr);
+    } else {
+        auto kern = ctrlbox_mfma_kernel<Model, KIND, false>;
+        hipLaunchKernelGGL(kern, dim3(1), dim3(64), bytes, st, a, ws);
+    }
+    return IRS_OK;
+}
+
+}  // namespace
+
+// 0 = the model does not fit one tile (not position controlled, or NHP + M > 16)
+size_t irs_ctrlbox_mfma_record_bytes(int model, int T) {
+    size_t r = 0;
+    IRS_DISPATCH_MODEL(model, {
+        if constexpr (has_u_into_x<Model>::value) {
+            using L = MfLayout<Model::NX, Model::NU>;
+            if constexpr (L::FITS) r = L::rec_doubles(T) * sizeof(double);
+        }
+    });
+    return r;
+}
+
+// bytes of LDS the records need to stay on chip (0 = model unsupported); > kLdsMax: a workspace is needed
+size_t irs_ctrlbox_mfma_lds_bytes(int model, int T) {
+    size_t r = 0;
+    IRS_DISPATCH_MODEL(model, {
+        if constexpr (has_u_into_x<Model>::value) {
+            using L = MfLayout<Model::NX, Model::NU>;
+            if constexpr (L::FITS) r = (L::rec_doubles(T) + L::small) * sizeof(double);
+        }
+    });
+    return r;
+}
+
+int irs_ctrlbox_mfma_launch(int model, const BoxArgs& a, int kind, double* ws, size_t ws_bytes, hipStream_t st) {
+    int rc = IRS_ERR_UNSUPPORTED;
+    IRS_DISPATCH_MODEL(model, {
+        if constexpr (has_u_into_x<Model>::value) {
+            if constexpr (MfLayout<Model::NX, Model::NU>::FITS) {
+                rc = kind == KIND_ABS_M ? launch_ctrlbox_mfma<Model, KIND_ABS_M>(a, ws, ws_bytes, st)
+                                        : launch_ctrlbox_mfma<Model, KIND_REL_M>(a, ws, ws_bytes, st);
+            } else {
+                irs_set_error("irs_quasistatic_box_descent: model %d does not fit the 16 x 16 tile", model);
+            }
+        } else {
+            irs_set_error("irs_quasistatic_box_descent: model %d is not position controlled", model);
+        }
+    });
+    return rc;
+}

@@ -188,19 +188,35 @@ class DeviceModel:
               "irs_tvlqr_box_descent")
         return o
 
-    SOLVER_AUTO, SOLVER_ADMM, SOLVER_ACTIVE_SET = 0, 1, 2
+    SOLVER_AUTO, SOLVER_ADMM, SOLVER_ACTIVE_SET, SOLVER_ACTIVE_SET_MFMA = 0, 1, 2, 3
 
     def quasistatic_descent_supported(self, T, solver=1):
-        return 0 < self.lib.irs_quasistatic_box_lds_bytes(self.model_id, int(T), int(solver)) <= self.BOX_LDS_LIMIT
+        """Whether `solver` can run horizon T (3: always, for models that fit the matrix-core tile -- beyond
+        the LDS-resident size its records go to a workspace in HBM; 1, 2: while their data fit LDS)."""
+        lds = self.lib.irs_quasistatic_box_lds_bytes(self.model_id, int(T), int(solver))
+        if int(solver) == 3:
+            return lds > 0
+        return 0 < lds <= self.BOX_LDS_LIMIT
+
+    def _descent_workspace(self, T, solver, device):
+        need = self.lib.irs_quasistatic_descent_workspace_bytes(self.model_id, int(T), int(solver))
+        if need == 0:
+            return None
+        ws = self._ws.get(("descent", device))
+        if ws is None or ws.numel() < need:
+            ws = torch.empty((need,), dtype=torch.uint8, device=device)
+            self._ws[("descent", device)] = ws
+        return ws
 
     def quasistatic_box_descent(self, At, Bt, ct, Q, Qd, R, xd_trj, x0, x_lo=None, x_hi=None, u_lo=None,
                                 u_hi=None, du_lo=None, du_hi=None, solver=0, rho=10.0, relax=1.6,
                                 max_iter=5000, eps=1e-8, out=None, act=None):
         """IrsLqrQuasistatic.local_descent after get_TV_matrices (irs_lqr_quasistatic.py:286-345) +
         eval_cost.  Bounds are absolute per-time rows ((T+1,n) / (T,m)) or None.  solver: 0 auto,
-        1 ADMM, 2 active set (one control box, no x bounds).  `act` (T,m) f64 in {-1,0,+1}, in/out: the
-        active set the first tail starts from / converged to (hand it from one iteration's descent to the
-        next; zeros = cold start).  Returns dict(x_new, u_new, cost, info[3])."""
+        1 ADMM, 2 active set (one control box, no x bounds; lanes, LDS-resident), 3 the same on matrix-core
+        tiles (any horizon).  `act` (T,m) f64 in {-1,0,+1}, in/out: the active set the first tail starts
+        from / converged to (hand it from one iteration's descent to the next; zeros = cold start).
+        Returns dict(x_new, u_new, cost, info[3])."""
         T = At.shape[0]
         dev = At.device
         o = out
@@ -213,12 +229,14 @@ class DeviceModel:
                          (u_hi, (T, self.m)), (du_lo, (T, self.m)), (du_hi, (T, self.m))):
             assert b is None or tuple(b.shape) == shape, (tuple(b.shape), shape)
         assert act is None or tuple(act.shape) == (T, self.m)
-        check(self.lib.irs_quasistatic_box_descent_ws(
+        ws = self._descent_workspace(T, solver, dev) if int(solver) in (0, 3) else None
+        check(self.lib.irs_quasistatic_box_descent_wsx(
             self.model_id, self._p, self._np, T, _ptr(At, F64), _ptr(Bt, F64), _ptr(ct, F64), _ptr(Q, F64),
             _ptr(Qd, F64), _ptr(R, F64), _ptr(xd_trj, F64), _ptr(x0, F64), _ptr(x_lo, F64), _ptr(x_hi, F64),
             _ptr(u_lo, F64), _ptr(u_hi, F64), _ptr(du_lo, F64), _ptr(du_hi, F64), int(solver), float(rho),
             float(relax), int(max_iter), float(eps), _ptr(o["x_new"], F64), _ptr(o["u_new"], F64), _ptr(o["cost"], F64),
-            o["info"].data_ptr(), _ptr(act, F64), _stream()), "irs_quasistatic_box_descent_ws")
+            o["info"].data_ptr(), _ptr(act, F64), ws.data_ptr() if ws is not None else None,
+            ws.numel() if ws is not None else 0, _stream()), "irs_quasistatic_box_descent_wsx")
         return o
 
     # ---- CEM baseline -------------------------------------------------------

@@ -73,7 +73,7 @@ class IrsLqrQuasistaticParameters:
 
         # ---- extensions (absent in the reference) ----
         self.device_rng_seed = None     # int: draw the perturbations on the device
-        self.qp_solver = 0              # 0 auto, 1 ADMM, 2 active set (include/irs_hip.h)
+        self.qp_solver = 0              # 0 auto, 1 ADMM, 2 active set (lanes), 3 active set (matrix-core tiles)
         self.qp_rho = 100.0             # ADMM penalty / iteration limit / tolerance of the bounded QPs
         self.qp_max_iter = 20000
         self.qp_eps = 1e-9
@@ -93,9 +93,15 @@ class IrsLqrQuasistatic(QuasistaticOptimizerBase):
         one_box = self.x_bounds_abs is None and (self.u_bounds_abs is None or self.u_bounds_rel is None)
         self._solver = int(getattr(params, "qp_solver", 0))
         if self._solver == 0:
-            self._solver = 2 if one_box and dm.quasistatic_descent_supported(params.T, 2) else 1
+            # one control box: the exact active-set method -- on matrix-core tiles (any horizon: beyond the
+            # LDS-resident size its records move to HBM) where the model fits the tile, else on lanes
+            self._solver = 1
+            if one_box:
+                self._solver = 3 if dm.quasistatic_descent_supported(params.T, 3) else (
+                    2 if dm.quasistatic_descent_supported(params.T, 2) else 1)
         if not dm.quasistatic_descent_supported(params.T, self._solver):
-            raise NotImplementedError("horizon T=%d does not fit the LDS-resident QP factorisation" % params.T)
+            raise NotImplementedError("horizon T=%d does not fit the LDS-resident QP factorisation of solver %d"
+                                      % (params.T, self._solver))
         self._setup(q_dynamics, params, params.x_trj_d)
         self._act = None
         self._idx = torch.as_tensor(np.asarray(self.indices_u_into_x), device=self._x0.device)
@@ -295,7 +301,7 @@ class IrsLqrQuasistatic(QuasistaticOptimizerBase):
     def _local_descent_dev(self, x_trj, u_trj):
         At, Bt, ct = self._get_TV_matrices_dev(x_trj, u_trj)
         p = self.params
-        if self._solver == 2 and getattr(self, "_act", None) is None:
+        if self._solver in (2, 3) and getattr(self, "_act", None) is None:
             # the active set of the first tail, handed from one iteration's descent to the next: consecutive
             # iterations bind nearly the same bounds (the QP's solution does not depend on the start)
             self._act = torch.zeros((self.T, self.dim_u), dtype=dev.F64, device=x_trj.device)
@@ -304,7 +310,7 @@ class IrsLqrQuasistatic(QuasistaticOptimizerBase):
                                              solver=self._solver, rho=getattr(p, "qp_rho", 100.0),
                                              max_iter=getattr(p, "qp_max_iter", 20000),
                                              eps=getattr(p, "qp_eps", 1e-9),
-                                             act=self._act if self._solver == 2 else None)
+                                             act=self._act if self._solver in (2, 3) else None)
         self._last = dict(At=At, Bt=Bt, ct=ct, info=o["info"])
         return o["x_new"], o["u_new"], o["cost"]
 

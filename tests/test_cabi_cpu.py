@@ -75,6 +75,12 @@ def test_argument_validation_without_gpu(lib):
     assert 0 < lib.irs_quasistatic_box_lds_bytes(4, 50, 2) <= 160 * 1024 - 512
     assert lib.irs_quasistatic_box_lds_bytes(4, 80, 2) > 160 * 1024 - 512   # planar hand: T <= 52 on chip
     assert 0 < lib.irs_quasistatic_box_lds_bytes(5, 120, 2) <= 160 * 1024 - 512   # box pivoting: its script's horizon fits
+    # the matrix-core active-set solver (3): on chip at the benchmark horizon, a workspace beyond it
+    assert 0 < lib.irs_quasistatic_box_lds_bytes(4, 50, 3) <= 160 * 1024 - 512
+    assert lib.irs_quasistatic_descent_workspace_bytes(4, 50, 3) == 0
+    assert lib.irs_quasistatic_descent_workspace_bytes(4, 120, 0) >= 120 * (192 + 144) * 8
+    assert lib.irs_quasistatic_descent_workspace_bytes(5, 120, 3) == 0            # box pivoting, T = 120: on chip
+    assert lib.irs_quasistatic_box_lds_bytes(0, 50, 3) == 0 and lib.irs_quasistatic_descent_workspace_bytes(0, 50, 3) == 0
     assert lib.irs_smooth_finalize_ws(4, ph, 12, 2, 50, 100, one, one, one, one, one, one, one, one, 64, None) == -1
     assert lib.irs_cem_rollout_costs_quasistatic(4, ph, 12, 10, 0, one, one, one, one, one, one, one, None) == -1
     assert lib.irs_model_info(11, None, None, None) != 0                     # ids 0..10 are registered

@@ -17,6 +17,17 @@ from oracle import irs_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
+# the stated fp32 tolerance of the sample pass against the f64 oracle on identical samples;
+# measured on the device: ~1e-6 for the analytic AND the contact models (tools/contact_tolerance_probe.py)
+FP32_TOL = dict(rtol=1e-4, atol=2e-5)
+
+
+@pytest.fixture(params=[2, 3], ids=["lanes", "mfma"])
+def as_solver(request):
+    """The two device implementations of the exact active-set descent (include/irs_hip.h, `solver`):
+    2 = ctrlbox.hip (lanes + LDS), 3 = ctrlbox_mfma.hip (matrix-core tiles).  Same method, same answers."""
+    return request.param
+
 TOL_AB = dict(rtol=1e-4, atol=2e-5)
 
 
@@ -582,8 +593,12 @@ def test_box_descent_vs_oracle(amd, T, steer, ubnd):
 
 
 def test_box_descent_without_active_bounds_equals_riccati(amd):
-    """Genuine but never-active bounds: the ADMM path must land on the unconstrained Riccati
-    descent (pendulum swing-up, |x| stays far below the +-100 box)."""
+    """Genuine but never-active bounds (pendulum swing-up, |x| stays far below the +-100 box).  Every FINITE
+    entry of xbound / ubound is a genuine bound -- no magnitude threshold: the host class runs the Riccati
+    descent, checks every tail's unconstrained plan against the box and keeps the result when all lie inside
+    (then it IS the solution of the bounded QPs); the ADMM kernel on the same problem lands on the same
+    descent; and a bound the plans do cross switches the host class to the bounded kernel."""
+    from irs_mpc_amd import device as dev
     T = 40
     params = pend_params(amd, T)
     sol_u = amd.IrsLqrExact(amd.PendulumDynamics(0.05), params)
@@ -592,10 +607,24 @@ def test_box_descent_without_active_bounds_equals_riccati(amd):
     params.xbound = [-np.full(2, 100.0), np.full(2, 100.0)]
     params.ubound = np.array([[-100.0], [100.0]])
     sol_b = amd.IrsLqrExact(amd.PendulumDynamics(0.05), params)
+    assert sol_b._box_bounds() is not None                       # 100 is a bound, not "none"
     xb, ub = sol_b.local_descent(sol_b.x_trj, sol_b.u_trj)
-    assert sol_b._box_used and int(sol_b._last["box_info"][2].item()) == 0
-    np.testing.assert_allclose(ub, uu, rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(xb, xu, rtol=1e-5, atol=1e-5)
+    assert not sol_b._box_used                                   # ... that no tail plan touches
+    np.testing.assert_array_equal(ub, uu)
+    # the bounded kernel itself on this problem == the Riccati descent
+    L = sol_b._last
+    o = sol_b._dm.tvlqr_box_descent(L["At"], L["Bt"], L["ct"], sol_b._Q, sol_b._Qd, sol_b._R, sol_b._xd,
+                                    dev.to_dev(sol_b.x_trj[0]), *sol_b._box_bounds(), alpha_R=0.5, eps=1e-9)
+    assert int(o["info"][2].item()) == 0
+    np.testing.assert_allclose(o["u_new"].cpu().numpy(), uu, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(o["x_new"].cpu().numpy(), xu, rtol=1e-5, atol=1e-5)
+    # a torque limit the swing-up does cross: the plans leave the box, the bounded kernel takes over
+    lim = 0.5 * np.abs(uu).max()
+    params.ubound = np.array([[-lim], [lim]])
+    sol_c = amd.IrsLqrExact(amd.PendulumDynamics(0.05), params)
+    xc, uc = sol_c.local_descent(sol_c.x_trj, sol_c.u_trj)
+    assert sol_c._box_used and int(sol_c._last["box_info"][2].item()) == 0
+    assert np.abs(uc).max() <= lim + 1e-6 and np.abs(uc - uu).max() > 1e-3
 
 
 def test_bicycle_exact_csv_end_to_end(amd, golden_dir):
@@ -757,9 +786,9 @@ def test_planar_hand_zero_order_B_decoupled_vs_oracle(amd):
     assert int(o["info"].abs().sum().item()) == 0
     Ao, Bo, co = orc.zero_order_B_decoupled(sys_o, x_trj, u_trj, du.astype(np.float64))
     np.testing.assert_allclose(At.cpu().numpy(), Ao, rtol=0, atol=0)
-    # f32 sample path incl. 50 PGS sweeps per sample vs the f64 oracle
-    np.testing.assert_allclose(Bt.cpu().numpy(), Bo, rtol=0, atol=2e-4)
-    np.testing.assert_allclose(ct.cpu().numpy(), co, rtol=0, atol=2e-4)
+    # f32 sample path (exact dual solve per sample) vs the f64 oracle
+    np.testing.assert_allclose(Bt.cpu().numpy(), Bo, **FP32_TOL)
+    np.testing.assert_allclose(ct.cpu().numpy(), co, **FP32_TOL)
     # the object rows of B see the contacts: pushing the fingers in moves the disc
     assert np.abs(Bo[:, HAND.PERM[:3], :]).max() > 0.05
 
@@ -785,8 +814,8 @@ def test_planar_hand_first_order_decoupled_vs_oracle(amd):
     Ao, Bo, co = orc.first_order_B_decoupled(sys_o, x_trj, u_trj, du.astype(np.float64))
     At, Bt, ct = o["At"].cpu().numpy(), o["Bt"].cpu().numpy(), o["ct"].cpu().numpy()
     np.testing.assert_allclose(At, Ao, rtol=0, atol=0)
-    np.testing.assert_allclose(Bt, Bo, rtol=0, atol=2e-3)
-    np.testing.assert_allclose(ct, co, rtol=0, atol=2e-3)
+    np.testing.assert_allclose(Bt, Bo, **FP32_TOL)
+    np.testing.assert_allclose(ct, co, **FP32_TOL)
     assert np.abs(Bo[:, HAND.PERM[:3], :]).max() > 0.05
     # the estimator agrees with the zero-order one to Monte-Carlo accuracy (same smoothed dynamics)
     Az, Bz, cz = orc.zero_order_B_decoupled(sys_o, x_trj, u_trj, du.astype(np.float64))
@@ -878,12 +907,12 @@ def test_planar_hand_exact_contact_solver_vs_oracle(amd):
     assert int(o["info"].abs().sum().item()) == 0
     Ao, Bo, co = orc.zero_order_B_decoupled(sys_o, x_trj, u_trj, du.astype(np.float64))
     np.testing.assert_allclose(o["At"].cpu().numpy(), Ao, rtol=0, atol=0)
-    np.testing.assert_allclose(o["Bt"].cpu().numpy(), Bo, rtol=0, atol=3e-4)      # f32 lanes vs the f64 oracle
-    np.testing.assert_allclose(o["ct"].cpu().numpy(), co, rtol=0, atol=3e-4)
+    np.testing.assert_allclose(o["Bt"].cpu().numpy(), Bo, **FP32_TOL)      # f32 lanes vs the f64 oracle
+    np.testing.assert_allclose(o["ct"].cpu().numpy(), co, **FP32_TOL)
     o1 = dm.smooth(SMOOTH_FIRST_ORDER, xd, ud, None, dev.to_dev(du, dev.F32))
     _, B1, c1 = orc.first_order_B_decoupled(sys_o, x_trj, u_trj, du.astype(np.float64))
-    np.testing.assert_allclose(o1["Bt"].cpu().numpy(), B1, rtol=0, atol=3e-3)     # borderline rows: O(1)/N each
-    np.testing.assert_allclose(o1["ct"].cpu().numpy(), c1, rtol=0, atol=3e-3)
+    np.testing.assert_allclose(o1["Bt"].cpu().numpy(), B1, **FP32_TOL)     # borderline rows: O(1)/N each
+    np.testing.assert_allclose(o1["ct"].cpu().numpy(), c1, **FP32_TOL)
     with pytest.raises(ValueError):
         amd.PlanarHandDynamics(0.1, contact_solver="nope")
 
@@ -936,8 +965,8 @@ def test_box_pivot_exact_solver_random_states(amd):
     du = (0.05 * rng.normal(size=(T, Ns, 2))).astype(np.float32)
     o = sys_d.dm().smooth(SMOOTH_ZERO_ORDER_B, dev.to_dev(x_trj), dev.to_dev(u_trj), None, dev.to_dev(du, dev.F32))
     Ao, Bo, co = orc.zero_order_B_decoupled(sys_o, x_trj, u_trj, du.astype(np.float64))
-    np.testing.assert_allclose(o["Bt"].cpu().numpy(), Bo, rtol=0, atol=2e-3)     # Kp = 5e4: f32 steps of a stiff hand
-    np.testing.assert_allclose(o["ct"].cpu().numpy(), co, rtol=0, atol=2e-3)
+    np.testing.assert_allclose(o["Bt"].cpu().numpy(), Bo, **FP32_TOL)     # Kp = 5e4: f32 steps of a stiff hand
+    np.testing.assert_allclose(o["ct"].cpu().numpy(), co, **FP32_TOL)
     # box pushing (2 rows): the exact functor exists too and is the default
     assert amd.BoxPushingDynamics(0.1).contact_solver == "exact"
     assert amd.BoxPushingDynamics(0.1).device_model != amd.BoxPushingDynamics(0.1, contact_solver="pgs").device_model
@@ -1021,7 +1050,7 @@ def _hand_problem(amd, T, N, seed):
 
 
 @pytest.mark.parametrize("bounds", ["abs", "rel", "abs+rel+x"])
-def test_quasistatic_box_descent_vs_oracle(amd, bounds):
+def test_quasistatic_box_descent_vs_oracle(amd, bounds, as_solver):
     """IrsLqrQuasistatic.local_descent after get_TV_matrices (irs_lqr_quasistatic.py:286-345): du cost,
     per-time trust-region bounds, T re-solved tail QPs, true (contact) dynamics in the loop."""
     from irs_mpc_amd import device as dev
@@ -1044,7 +1073,7 @@ def test_quasistatic_box_descent_vs_oracle(amd, bounds):
     if bounds in ("abs", "rel"):
         # the exact active-set solver on the same QPs: device == its oracle twin == the ADMM answer
         o2 = dm.quasistatic_box_descent(*[dev.to_dev(a) for a in (At, Bt, ct, Q, Qd, R, xd, x0)], *rows_d,
-                                        solver=2, max_iter=2000, eps=1e-10)
+                                        solver=as_solver, max_iter=2000, eps=1e-10)
         i2 = o2["info"].cpu().numpy()
         assert i2[0] == 0 and i2[2] == 0, i2
         lo, hi = (rows[2], rows[3]) if bounds == "abs" else (rows[4], rows[5])
@@ -1101,8 +1130,8 @@ def test_irs_lqr_quasistatic_host_twin(amd):
     xo, uo, _ = orc.local_descent_quasistatic(sys_o, At, Bt, ct, Q, Qd, R, x0, xd, *rows, rho=100.0,
                                               max_iter=40000, eps=1e-10, relax=1.6)
     # B is fitted from f32 one-step evaluations on the device: the QP data differ at the 1e-4 level
-    np.testing.assert_allclose(un, uo, rtol=0, atol=5e-3)
-    np.testing.assert_allclose(xn, xo, rtol=0, atol=5e-3)
+    np.testing.assert_allclose(un, uo, rtol=0, atol=5e-4)
+    np.testing.assert_allclose(xn, xo, rtol=0, atol=5e-4)
     c0 = sol.cost
     sol.iterate(3)
     assert len(sol.cost_all_list) == 5 and sol.cost_best < c0
@@ -1207,7 +1236,7 @@ def test_quasistatic_example_runner(amd, argv, monkeypatch, capsys):
         assert min(hist[1:]) < hist[0]
 
 
-def test_quasistatic_active_set_warm_start_across_iterations(amd):
+def test_quasistatic_active_set_warm_start_across_iterations(amd, as_solver):
     """irs_quasistatic_box_descent_ws: the active set of the first tail handed from one descent to the
     next.  Two consecutive iterations of the planar-hand problem (the second linearised around the first
     one's result): warm and cold start give the same trajectory (the QP's solution does not depend on
@@ -1230,10 +1259,10 @@ def test_quasistatic_active_set_warm_start_across_iterations(amd):
         At, Bt, ct = orc.zero_order_B_decoupled(sys_o, x_trj, u_trj, du)
         rows = orc.quasistatic_bounds(x_trj, idx, None, ub, None)
         args = [dev.to_dev(a) for a in (At, Bt, ct, Q, Qd, R, xd, x0)]
-        cold = dm.quasistatic_box_descent(*args, u_lo=dev.to_dev(rows[2]), u_hi=dev.to_dev(rows[3]), solver=2,
+        cold = dm.quasistatic_box_descent(*args, u_lo=dev.to_dev(rows[2]), u_hi=dev.to_dev(rows[3]), solver=as_solver,
                                           max_iter=2000, eps=1e-10)
         u_cold = cold["u_new"].cpu().numpy().copy()
-        warm = dm.quasistatic_box_descent(*args, u_lo=dev.to_dev(rows[2]), u_hi=dev.to_dev(rows[3]), solver=2,
+        warm = dm.quasistatic_box_descent(*args, u_lo=dev.to_dev(rows[2]), u_hi=dev.to_dev(rows[3]), solver=as_solver,
                                           max_iter=2000, eps=1e-10, act=act_d)
         info = warm["info"].cpu().numpy()
         assert info[0] == 0 and info[2] == 0, info
@@ -1246,16 +1275,44 @@ def test_quasistatic_active_set_warm_start_across_iterations(amd):
         x_trj, u_trj = xo, uo
     # garbage in the warm start (and a pin at an infinite bound) is harmless
     junk = dev.to_dev(rng.integers(-1, 2, size=(T, 4)).astype(np.float64) * 3.0)
-    again = dm.quasistatic_box_descent(*args, u_lo=dev.to_dev(rows[2]), u_hi=dev.to_dev(rows[3]), solver=2,
+    again = dm.quasistatic_box_descent(*args, u_lo=dev.to_dev(rows[2]), u_hi=dev.to_dev(rows[3]), solver=as_solver,
                                        max_iter=2000, eps=1e-10, act=junk)
     np.testing.assert_allclose(again["u_new"].cpu().numpy(), u_cold, rtol=0, atol=1e-8)
-    free = dm.quasistatic_box_descent(*args, solver=2, max_iter=2000, eps=1e-10, act=junk.clone())
-    none = dm.quasistatic_box_descent(*args, solver=2, max_iter=2000, eps=1e-10)
+    free = dm.quasistatic_box_descent(*args, solver=as_solver, max_iter=2000, eps=1e-10, act=junk.clone())
+    none = dm.quasistatic_box_descent(*args, solver=as_solver, max_iter=2000, eps=1e-10)
     np.testing.assert_allclose(free["u_new"].cpu().numpy(), none["u_new"].cpu().numpy(), rtol=0, atol=1e-9)
 
 
+@pytest.mark.parametrize("T,kind", [(64, "abs"), (120, "abs"), (120, "rel")])
+def test_quasistatic_descent_long_horizon(amd, T, kind):
+    """Horizons beyond the LDS-resident size (planar hand: 52 steps on lanes, 55 on tiles): the matrix-core
+    solver keeps its per-step records in an HBM workspace instead -- the reference has no horizon limit
+    (irs_lqr_quasistatic.py:325-345).  Device == the oracle twin; the host twin picks it by itself."""
+    from irs_mpc_amd import device as dev
+    sys_d, sys_o, x0, u_trj, x_trj, _, (At, Bt, ct), (Q, Qd, R, xd) = _hand_problem(amd, T, 150, 40 + T)
+    dm = sys_d.dm()
+    assert not dm.quasistatic_descent_supported(T, 2) and dm.quasistatic_descent_supported(T, 3)
+    assert dm.lib.irs_quasistatic_descent_workspace_bytes(dm.model_id, T, 3) > 0
+    idx = sys_o.indices_u_into_x
+    if kind == "abs":
+        rows = orc.quasistatic_bounds(x_trj, idx, None, np.array([-np.ones(4) * 0.05, np.ones(4) * 0.05]), None)
+        lo, hi = rows[2], rows[3]
+        b = dict(u_lo=dev.to_dev(lo), u_hi=dev.to_dev(hi))
+    else:
+        lo, hi = np.full((T, 4), -0.03), np.full((T, 4), 0.03)
+        b = dict(du_lo=dev.to_dev(lo), du_hi=dev.to_dev(hi))
+    xa, ua, _ = orc.local_descent_quasistatic_as(sys_o, At, Bt, ct, Q, Qd, R, x0, xd, lo, hi, kind)
+    o = dm.quasistatic_box_descent(*[dev.to_dev(a) for a in (At, Bt, ct, Q, Qd, R, xd, x0)], solver=0,
+                                   max_iter=2000, eps=1e-10, **b)
+    info = o["info"].cpu().numpy()
+    assert info[0] == 0 and info[2] == 0, info
+    np.testing.assert_allclose(o["u_new"].cpu().numpy(), ua, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(o["x_new"].cpu().numpy(), xa, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(float(o["cost"].item()), orc.eval_cost_quasistatic(xa, ua, xd, Q, Qd, R, idx), rtol=1e-8)
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
-def test_quasistatic_active_set_random_problems(amd, seed):
+def test_quasistatic_active_set_random_problems(amd, seed, as_solver):
     """The active-set descent on randomised planar-hand problems (nominal trajectory, goal, bound
     widths, cost weights): device == oracle twin, both kinds, including tails that need the primal
     safeguard."""
@@ -1283,7 +1340,7 @@ def test_quasistatic_active_set_random_problems(amd, seed):
         assert all(st[1] >= 0 for st in stats)
         kw = dict(u_lo=dev.to_dev(lo), u_hi=dev.to_dev(hi)) if kind == "abs" else \
             dict(du_lo=dev.to_dev(lo), du_hi=dev.to_dev(hi))
-        o = dm.quasistatic_box_descent(*[dev.to_dev(a) for a in (At, Bt, ct, Q, Qd, R, xd, x0)], solver=2,
+        o = dm.quasistatic_box_descent(*[dev.to_dev(a) for a in (At, Bt, ct, Q, Qd, R, xd, x0)], solver=as_solver,
                                        max_iter=2000, eps=1e-10, **kw)
         info = o["info"].cpu().numpy()
         assert info[0] == 0 and info[2] == 0, (kind, info)
@@ -1329,8 +1386,8 @@ def test_box_pivot_quasistatic_iteration_vs_oracle(amd):
     assert int(o["info"].abs().sum().item()) == 0
     At, Bt, ct = orc.zero_order_B_decoupled(sys_o, x_trj, u_trj, du.astype(np.float64))
     np.testing.assert_allclose(o["At"].cpu().numpy(), At, rtol=0, atol=0)
-    # f32 samples through a stiff (kp = 5e4) contact QP: looser than the planar hand
-    np.testing.assert_allclose(o["Bt"].cpu().numpy(), Bt, rtol=0, atol=3e-3)
+    # f32 samples through a stiff (kp = 5e4) contact QP
+    np.testing.assert_allclose(o["Bt"].cpu().numpy(), Bt, **FP32_TOL)
     Q = np.diag(orc.BoxPivotOracle.pack([5, 5, 50], [0, 0]))
     Qd, R = Q.copy(), 1e3 * np.eye(2)
     xd = np.tile(orc.BoxPivotOracle.pack([1.0, 1.0, -np.pi / 2], [-0.5, 0.5]), (T + 1, 1))
@@ -1352,7 +1409,7 @@ def test_box_pivot_quasistatic_iteration_vs_oracle(amd):
                                            ("box_pivoting", "pgs"), ("box_pivoting", "exact"), ("box_pushing", "pgs"),
                                            ("box_pushing", "exact")])
 @pytest.mark.parametrize("T", [7, 16, 23])
-def test_quasistatic_descent_outputs_are_self_consistent(amd, system, solver, T):
+def test_quasistatic_descent_outputs_are_self_consistent(amd, system, solver, T, as_solver):
     """Whatever the model, the contact solver and the parity of the horizon: the trajectory the active-set
     descent returns is a rollout of the device dynamics under the controls it returns, and the cost it
     returns is eval_cost (irs_lqr_quasistatic.py:153-194) of exactly that trajectory -- values that live in
@@ -1385,7 +1442,7 @@ def test_quasistatic_descent_outputs_are_self_consistent(amd, system, solver, T)
     bounds = dict(u_lo=(nom - w).contiguous(), u_hi=(nom + w).contiguous()) if kind == "abs" else \
         dict(du_lo=dev.to_dev(np.full((T, m), -w)), du_hi=dev.to_dev(np.full((T, m), w)))
     out = dm.quasistatic_box_descent(o["At"], o["Bt"], o["ct"], dev.to_dev(Q), dev.to_dev(Qd), dev.to_dev(R),
-                                     dev.to_dev(xd), dev.to_dev(x0), solver=2, max_iter=2000, eps=1e-10, **bounds)
+                                     dev.to_dev(xd), dev.to_dev(x0), solver=as_solver, max_iter=2000, eps=1e-10, **bounds)
     info = out["info"].cpu().numpy()
     assert info[0] == 0 and info[2] == 0, info
     xn, un = out["x_new"].cpu().numpy(), out["u_new"].cpu().numpy()
@@ -1470,8 +1527,8 @@ def test_irs_lqr_quasistatic_zero_order_AB_mode(amd):
     dx, du = np.stack(dx).astype(np.float32).astype(np.float64), np.stack(du).astype(np.float32).astype(np.float64)
     Ao, Bo, co = orc.zero_order_AB_damped_decoupled(sys_o, sol.x_trj, sol.u_trj, dx, du)
     np.testing.assert_allclose(At, Ao, rtol=0, atol=0)
-    np.testing.assert_allclose(Bt, Bo, rtol=0, atol=5e-4)          # f32 contact steps
-    np.testing.assert_allclose(ct, co, rtol=0, atol=5e-4)
+    np.testing.assert_allclose(Bt, Bo, rtol=0, atol=1e-4)          # f32 contact steps
+    np.testing.assert_allclose(ct, co, rtol=0, atol=1e-4)
     c0 = sol.cost
     sol.iterate(2)
     assert sol.cost_best < c0
@@ -1517,7 +1574,7 @@ def test_quasistatic_gradient_modes_without_decoupling(amd, mode):
         if mode == "zero_order_B":
             du = du.astype(np.float32).astype(np.float64)
             Ao, Bo, co = orc.zero_order_B_decoupled(sys_o, sol.x_trj, sol.u_trj, du, decouple=False)
-            tolA, tolB = 1e-8, 5e-4
+            tolA, tolB = 1e-8, 5e-5
         else:
             Ao, Bo, co = orc.first_order_B_decoupled(sys_o, sol.x_trj, sol.u_trj, du, decouple=False)
             tolA, tolB = 1e-8, 1e-8      # f64 lanes on the f64 draws
@@ -1557,7 +1614,7 @@ def test_quasistatic_simulator_gradient_modes(amd, mode):
         du = np.stack([np.random.normal(0, p.std_u_initial, size=[N, 4]) for _ in range(T)])
         du = du.astype(np.float32).astype(np.float64)
         Ao, Bo, co = orc.first_order_B_decoupled(sys_o, sol.x_trj, sol.u_trj, du)
-        tol = 3e-3
+        tol = 5e-5           # f32 lanes vs the f64 oracle; no flipped samples with the exact step QP
     else:
         Ao, Bo, co = orc.exact_contact_TV(sys_o, sol.x_trj, sol.u_trj, decouple=True)
         tol = 1e-8
@@ -1631,11 +1688,11 @@ def test_planar_hand_full_size_properties(amd, mode_name):
         us = u_np[t] + sub[t].cpu().numpy().astype(np.float64)
         if mode_name == "first_order":
             Bo = sys_o.jacobian_xu_batch(np.tile(x_np[t], (1000, 1)), us)[:, :, 7:].mean(0)
-            tol = 6e-3          # borderline active-set classifications, f32 vs f64: O(1)/N each
+            tol = 5e-5          # f32 lanes vs the f64 oracle (exact step QP: no flipped samples)
         else:
             fn = sys_o.dynamics_batch(np.tile(x_np[t], (1000, 1)), us)
             Bo = orc.zero_order_B_fit(sub[t].cpu().numpy().astype(np.float64), fn - sys_o.dynamics(x_np[t], u_np[t]))
-            tol = 5e-4
+            tol = 5e-5
         Bo[HAND_IDX, :] = np.eye(4)
         np.testing.assert_allclose(o_sub["Bt"][t].cpu().numpy(), Bo, rtol=0, atol=tol)
 

@@ -1,6 +1,6 @@
-"""Times the quasistatic (du-cost, trust-region) descent of the planar hand at BASELINE's horizon:
-active-set solver (and ADMM with --admm: seconds per descent), u_bounds_abs vs u_bounds_rel.
-    python tools/time_quasistatic.py [T] [N] [--admm]"""
+"""Times the quasistatic (du-cost, one control box) descent at BASELINE's horizons: the two active-set
+solvers (2 = lanes + LDS, 3 = matrix-core tiles), u_bounds_abs vs u_bounds_rel vs none, cold start.
+    python tools/time_quasistatic.py [planar_hand|box_pivoting] [T] [N] [--admm]"""
 import os
 import sys
 import time
@@ -9,34 +9,37 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from irs_mpc_amd import PlanarHandDynamics, device as dev, _lib  # noqa: E402
+from irs_mpc_amd import device as dev, _lib  # noqa: E402
+import bench  # noqa: E402
 
 args = [v for v in sys.argv[1:] if not v.startswith("--")]
-T = int(args[0]) if len(args) > 0 else 50
-N = int(args[1]) if len(args) > 1 else 10000
-sysd = PlanarHandDynamics(0.1)
-dm = sysd.dm()
-parts = lambda obj, arm_l, arm_r: sysd.get_x_from_q_dict({"sphere": obj, "arm_left": arm_l, "arm_right": arm_r})
-uidx = sysd.get_u_indices_into_x()
-x0 = parts([0.0, 0.35, 0.0], [-np.pi / 4, -np.pi / 4], [np.pi / 4, np.pi / 4])
-u_trj = dev.to_dev(np.tile(x0[uidx], (T, 1)))
-q = parts([1e-3, 1e-3, 10.0], [1e-3, 1e-3], [1e-3, 1e-3])
-Q, Qd, R = dev.to_dev(np.diag(q)), dev.to_dev(np.diag(100 * q)), dev.to_dev(5.0 * np.eye(4))
-xd = dev.to_dev(np.tile(x0 + parts([0.3, -0.1, 0.5], [0, 0], [0, 0]), (T + 1, 1)))
-x0d = dev.to_dev(x0)
+name = args[0] if args else "planar_hand"
+T = int(args[1]) if len(args) > 1 else None
+N = int(args[2]) if len(args) > 2 else 10000
+w = bench.Workload(name, T)
+T = w.T
+dm = w.system.dm()
+m = dm.m
+Q, Qd, R = dev.to_dev(w.Q), dev.to_dev(w.Qd), dev.to_dev(w.R)
+xd, x0d, u_trj = dev.to_dev(w.xd), dev.to_dev(w.x0), dev.to_dev(w.u_trj)
 x_trj, _ = dm.rollout_cost(x0d, u_trj, Q, R, xd)
 g = torch.Generator(device="cuda").manual_seed(0)
-du = 0.3 * torch.randn((T, N, 4), generator=g, device="cuda", dtype=torch.float32)
+du = w.std_u * torch.randn((T, N, m), generator=g, device="cuda", dtype=torch.float32)
 o = dm.smooth(_lib.SMOOTH_ZERO_ORDER_B, x_trj, u_trj, None, du)
 At, Bt, ct = o["At"], o["Bt"], o["ct"]
-idx = torch.as_tensor(uidx, device="cuda")
+idx = torch.as_tensor(w.idx, device="cuda")
 nom = x_trj[:-1].index_select(1, idx).contiguous()
-cases = {"abs": dict(u_lo=(nom - 0.05).contiguous(), u_hi=(nom + 0.05).contiguous()),
-         "rel": dict(du_lo=torch.full((T, 4), -0.03, dtype=torch.float64, device="cuda"),
-                     du_hi=torch.full((T, 4), 0.03, dtype=torch.float64, device="cuda")),
+wa, wr = (0.05, 0.03) if name == "planar_hand" else (0.05, 0.015)
+cases = {"abs": dict(u_lo=(nom - wa).contiguous(), u_hi=(nom + wa).contiguous()),
+         "rel": dict(du_lo=torch.full((T, m), -wr, dtype=torch.float64, device="cuda"),
+                     du_hi=torch.full((T, m), wr, dtype=torch.float64, device="cuda")),
          "none": dict()}
-for name, b in cases.items():
-    for solver, label in ((2, "active-set"),) + (((1, "ADMM"),) if "--admm" in sys.argv else ()):
+ref = {}
+for cname, b in cases.items():
+    for solver, label in ((3, "mfma tiles"), (2, "lanes"),) + (((1, "ADMM"),) if "--admm" in sys.argv else ()):
+        if not dm.quasistatic_descent_supported(T, solver):
+            print("T=%d %-4s %-10s unsupported" % (T, cname, label))
+            continue
         kw = dict(solver=solver, rho=100.0, relax=1.6, max_iter=20000 if solver == 1 else 2000, eps=1e-9)
         out = dm.quasistatic_box_descent(At, Bt, ct, Q, Qd, R, xd, x0d, **b, **kw)
         torch.cuda.synchronize()
@@ -46,5 +49,7 @@ for name, b in cases.items():
             dm.quasistatic_box_descent(At, Bt, ct, Q, Qd, R, xd, x0d, **b, **kw, out=out)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
-        print("T=%d %-4s %-10s %9.3f ms/descent  cost %.6f  info %s"
-              % (T, name, label, dt * 1e3, float(out["cost"].item()), out["info"].cpu().numpy().tolist()), flush=True)
+        u = out["u_new"].cpu().numpy()
+        d = np.abs(u - ref.setdefault(cname, u)).max()
+        print("%s T=%d %-4s %-10s %9.3f ms/descent  cost %.6f  info %s  |u - first solver's| %.1e"
+              % (name, T, cname, label, dt * 1e3, float(out["cost"].item()), out["info"].cpu().numpy().tolist(), d), flush=True)
