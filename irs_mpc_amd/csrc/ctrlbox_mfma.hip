@@ -26,7 +26,7 @@
 // multipliers (rows NHP..) together.  The state never leaves the registers.
 //
 // Per-step records (G_t image, P~_t, active set, bounds, iterates) live in LDS when the horizon fits
-// (planar hand: T <= 55; box pivoting: T <= 200) and otherwise in a caller-supplied global workspace
+// (planar hand: T <= 55; box pivoting: T <= 125) and otherwise in a caller-supplied global workspace
 // (L2-resident; same code, slower) -- the reference has no horizon limit (irs_lqr_quasistatic.py:325-345).
 // f64 matrix and vector rates are equal on gfx950: what the tile buys is not flops but the absence of
 // LDS round trips and cross-lane traffic inside a step (ctrlbox.hip: 6 LDS phases, ~7000 cycles per
@@ -77,7 +77,8 @@ struct MfLayout {
     static constexpr int NS = NR + M, NH = NS + 1, NHP = (NH + 3) / 4 * 4, KA = NHP / 4;
     static constexpr bool FITS = NHP + M <= 16 && M <= 4;
     // doubles per time step: forward tile image, P~ image (lanes with col < NHP), 6 control vectors, Qs sd
-    static constexpr int GT = KA * 64, PT = KA * 4 * NHP;
+    // (the forward tile keeps its rows i < NHP + M only: index (4 s + k-group) * GR + i)
+    static constexpr int GR = NHP + M, GT = KA * 4 * GR, PT = KA * 4 * NHP;
     static __host__ __device__ size_t oG(int) { return 0; }
     static __host__ __device__ size_t oP(int T) { return (size_t)T * GT; }
     static __host__ __device__ size_t oV(int T) { return oP(T) + (size_t)(T + 1) * PT; }       // 6 x (T, M)
@@ -339,8 +340,8 @@ __global__ __launch_bounds__(64) void ctrlbox_mfma_kernel(BoxArgs a, double* gws
                 const int row = rg + 4 * r;
                 P[r] = (r < KA && row < NH && col < NH) ? Pn[r] : 0.0;
             }
-            // records: P~_t, and the forward tile G_t in A-operand register image -- element [i][k] at
-            // register k >> 2 of lane (k & 3) * 16 + i
+            // records: P~_t, and the forward tile G_t as its A-operand will be read -- element [i][k] belongs to
+            // register k >> 2 of lane (k & 3) * 16 + i, stored at k * GR + i
             if (col < NHP) {
 #pragma unroll
                 for (int r = 0; r < KA; ++r) Pt[(size_t)t * L::PT + (r * 4 + rg) * NHP + col] = P[r];
@@ -348,8 +349,8 @@ __global__ __launch_bounds__(64) void ctrlbox_mfma_kernel(BoxArgs a, double* gws
             double* G = Gt + (size_t)t * L::GT;
             if (col < NH) {
 #pragma unroll
-                for (int r = 0; r < KA; ++r) G[(col >> 2) * 64 + (col & 3) * 16 + (rg + 4 * r)] = Acl[r];
-                if (rg < M) G[(col >> 2) * 64 + (col & 3) * 16 + (NHP + rg)] = my_free ? Kb : D[RN];
+                for (int r = 0; r < KA; ++r) G[col * L::GR + (rg + 4 * r)] = Acl[r];        // (4 (col>>2) + (col&3)) = col
+                if (rg < M) G[col * L::GR + (NHP + rg)] = my_free ? Kb : D[RN];
             }
         }
         rsync();
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(64) void ctrlbox_mfma_kernel(BoxArgs a, double* gws
         auto fetch = [&](int t, double* gg, double& acx, double& bdx) {
             const double* G = Gt + (size_t)t * L::GT;
 #pragma unroll
-            for (int s = 0; s < KA; ++s) gg[s] = G[s * 64 + lane];
+            for (int s = 0; s < KA; ++s) gg[s] = col < L::GR ? G[(4 * s + rg) * L::GR + col] : 0.0;
             const int j = rg < M ? rg : 0;
             acx = act_[(size_t)t * M + j];
             bdx = acx < 0.0 ? lo_[(size_t)t * M + j] : hi_[(size_t)t * M + j];
