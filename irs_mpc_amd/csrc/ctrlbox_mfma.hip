@@ -36,10 +36,16 @@
 namespace {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+// the caller's (A, B, c) are read through GLOBAL-address-space pointers: a generic pointer makes them
+// flat loads, which count against lgkmcnt too -- every wait for an LDS read would then also wait for the
+// prefetch of the next step's data (measured: 1.8 us per backward step instead of ~0.5)
+typedef const __attribute__((address_space(1))) double* gptr_d;
 
 constexpr int kPdasIterM = 10;
 constexpr int KIND_ABS_M = 0, KIND_REL_M = 1;
 
+// 1/d: hardware estimate + two Newton steps (~1 ulp).  (The policy-evaluation form would forgive a cruder
+// gain in the cost-to-go, but the gain IS the control that is applied.)
 __device__ __forceinline__ double fast_rcp_m(double d) {
     double r = __builtin_amdgcn_rcp(d);
     r = fma(fma(-d, r, 1.0), r, r);
@@ -84,25 +90,33 @@ struct MfLayout {
     static __host__ __device__ size_t oV(int T) { return oP(T) + (size_t)(T + 1) * PT; }       // 6 x (T, M)
     static __host__ __device__ size_t oQ(int T) { return oV(T) + (size_t)6 * T * M; }          // (T+1, NR)
     static __host__ __device__ size_t rec_doubles(int T) { return oQ(T) + (size_t)(T + 1) * NR; }
-    // always in LDS: Qsym, Qdsym (NR^2), Rsym (M^2), sstart (NH), slack
-    static constexpr int small = 2 * NR * NR + M * M + NH + 16;
+    // always in LDS: Qsym, Qdsym (NR^2), Rsym (M^2), sstart (NH), uctl (M), slack
+    static constexpr int small = 2 * NR * NR + M * M + NH + M + 16;
 };
 
-// The f64 contact step needs hundreds of registers; out of line so that the solver's loops keep theirs.
-template <class Model>
-__device__ __noinline__ void true_step_m(const ModelParams& p, const double* x, const double* u, double* xn) {
-    Model::template step<double>(p, x, u, xn);
-}
-
+// TWO waves, two roles.  Wave 0 solves the tail QPs (everything below up to the MPC loop); wave 1 is the
+// PLANT: it owns the realised state, applies each tail's first control to the TRUE (contact) dynamics,
+// accumulates IrsLqrQuasistatic.eval_cost and hands the next start state back -- through two LDS vectors and
+// two workgroup barriers per tail.  The f64 contact step needs hundreds of registers; as a separate WAVE of
+// the same kernel (rather than an out-of-line FUNCTION called from the solver wave, as it used to be) it
+// cannot disturb the solver's registers: no call, no value live across one.  That is the fix of the
+// instantiation-dependent miscompute of the earlier kernels (wrong accumulated cost, `info`
+// never written, and -- once the solver kept per-lane pointers across the call -- wrong trajectories and a
+// GPU fault, all on the box-pivoting functor only): every symptom was a value of the CALLER that was live
+// across the call to the contact step, whose callee (compiled with inter-procedural register allocation,
+// 256 VGPRs + 222 AGPRs, no callee-saved registers) left the caller ~40 registers and a scratch frame to
+// park ~150 values in.
 template <class Model, int KIND, bool LDSREC>
-__global__ __launch_bounds__(64) void ctrlbox_mfma_kernel(BoxArgs a, double* gws) {
+__global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gws) {
     constexpr int NR = Model::NX, M = Model::NU;
     using L = MfLayout<NR, M>;
     constexpr int NS = L::NS, NH = L::NH, NHP = L::NHP, KA = L::KA, RN = L::KA;   // RN: register of rows NHP..NHP+3
     static_assert(L::FITS, "one 16 x 16 tile");
     constexpr double INF = __builtin_huge_val();
     extern __shared__ double lds[];
-    const int T = a.T, lane = threadIdx.x, col = lane & 15, rg = lane >> 4;
+    const int T = a.T, lane = threadIdx.x & 63, col = lane & 15, rg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // 0 solver, 1 plant
+    const double tol_ = a.eps;
 
     double* rec = LDSREC ? lds : gws;                       // per-step records
     double* sm = LDSREC ? lds + L::rec_doubles(T) : lds;    // small tables, always LDS
@@ -119,7 +133,8 @@ __global__ __launch_bounds__(64) void ctrlbox_mfma_kernel(BoxArgs a, double* gws
     double* Qsym = sm;
     double* Qdsym = Qsym + NR * NR;
     double* Rsym = Qdsym + NR * NR;
-    double* sstart = Rsym + M * M;                          // NH entries: s, then 1
+    double* sstart = Rsym + M * M;                          // NH entries: s, then 1   (plant -> solver)
+    double* uctl = sstart + NH;                             // M: the tail's first control, clipped (solver -> plant)
 
     // orders this wave's memory traffic on the records: LDS executes one wave's operations in issue order
     // (compiler barrier only); global records additionally need the stores drained and this CU's L1 dropped
@@ -134,10 +149,92 @@ __global__ __launch_bounds__(64) void ctrlbox_mfma_kernel(BoxArgs a, double* gws
         __builtin_amdgcn_wave_barrier();
     };
 
-    // ---- setup ------------------------------------------------------------------------
+    auto wg_barrier = [&]() {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    // ---- the plant wave ------------------------------------------------------------------
+    // barriers: S0 (the solver's tables are up), then per tail A (start state ready) and B (control ready)
+    if (wave == 1) {
+        double xr[NR], ur[M], xn[NR], up[M], ub[M];
+        if (lane == 0 && a.cost) a.cost[0] = __builtin_nan("");      // sentinel, like info (ctrlbox.hip)
+#pragma unroll
+        for (int i = 0; i < NR; ++i) xr[i] = a.x0[i];
+#pragma unroll
+        for (int j = 0; j < M; ++j) up[j] = 0.0;
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) a.x_new[i] = xr[i];
+        }
+        auto quad = [&](const double* Wq, const double* e, int Kd) -> double {
+            double q = 0.0;
+            for (int i = 0; i < Kd; ++i)
+                for (int j = 0; j < Kd; ++j) q += e[i] * Wq[i * Kd + j] * e[j];
+            return q;
+        };
+        // start state [x; x[idx]; 1]: each tail's first du is measured from the realised actuated position
+        // (tv_lqr.py:99-100 at the tail's local t = 0)
+        auto publish_start = [&]() {
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                double v = xr[0];
+#pragma unroll
+                for (int i = 1; i < NR; ++i) v = (i == Model::u_into_x(j)) ? xr[i] : v;
+                ub[j] = v;
+            }
+            if (lane < NH) {
+                double v = xr[0];
+#pragma unroll
+                for (int i = 1; i < NR; ++i) v = (i == lane) ? xr[i] : v;
+#pragma unroll
+                for (int j = 0; j < M; ++j) v = (NR + j == lane) ? ub[j] : v;
+                sstart[lane] = lane == NS ? 1.0 : v;
+            }
+        };
+        double cost = 0.0;
+        wg_barrier();                                       // S0
+        publish_start();
+        for (int tau = 0; tau < T; ++tau) {
+            wg_barrier();                                   // A(tau)
+            wg_barrier();                                   // B(tau): uctl holds the tail's first control
+#pragma unroll
+            for (int j = 0; j < M; ++j) ur[j] = KIND == KIND_ABS_M ? uctl[j] : ub[j] + uctl[j];
+            {   // IrsLqrQuasistatic.eval_cost (irs_lqr_quasistatic.py:153-194)
+                double e[NR], dv[M];
+#pragma unroll
+                for (int i = 0; i < NR; ++i) e[i] = xr[i] - a.xd[(size_t)tau * NR + i];
+#pragma unroll
+                for (int j = 0; j < M; ++j) dv[j] = ur[j] - (tau == 0 ? ub[j] : up[j]);
+                cost += quad(Qsym, e, NR) + quad(Rsym, dv, M);
+            }
+            Model::template step<double>(a.p, xr, ur, xn);
+#pragma unroll
+            for (int i = 0; i < NR; ++i) xr[i] = xn[i];
+#pragma unroll
+            for (int j = 0; j < M; ++j) up[j] = ur[j];
+            if (lane == 0) {
+#pragma unroll
+                for (int j = 0; j < M; ++j) a.u_new[(size_t)tau * M + j] = ur[j];
+#pragma unroll
+                for (int i = 0; i < NR; ++i) a.x_new[(size_t)(tau + 1) * NR + i] = xr[i];
+            }
+            publish_start();
+        }
+        {
+            double e[NR];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) e[i] = xr[i] - a.xd[(size_t)T * NR + i];
+            cost += quad(Qdsym, e, NR);
+        }
+        if (lane == 0 && a.cost) a.cost[0] = cost;
+        return;
+    }
+
+    // ---- the solver wave: setup ----------------------------------------------------------
     if (lane == 0) {
         a.info[0] = -1; a.info[1] = -1; a.info[2] = -1;     // sentinels: see ctrlbox.hip
-        if (a.cost) a.cost[0] = __builtin_nan("");
     }
     for (int q = lane; q < NR * NR; q += 64) {
         const int i = q / NR, j = q % NR;
@@ -206,33 +303,59 @@ __global__ __launch_bounds__(64) void ctrlbox_mfma_kernel(BoxArgs a, double* gws
     rsync();
 
     // ---- step data straight from the caller's (A, B, c): F_t in C/D layout, B~ in A-operand layout ----
-    auto load_F = [&](int t, v4d& F, double& Ba) {
-        const double* At = a.At + (size_t)t * NR * NR;
-        const double* Bt = a.Bt + (size_t)t * NR * M;
+    // Which array (and where) each of this lane's five elements comes from is fixed: resolved ONCE into
+    // (pointer, stride per time step, constant, is-a-load), so that a step's loads are five unconditional
+    // global loads (a constant element reads a.ct[0] and discards it) -- no divergent branches in the loops.
+    gptr_d fp[5];
+    int fstr[5];
+    double fc[5];
+    bool fld[5];
+    {
+        const gptr_d gA = (gptr_d)a.At, gB = (gptr_d)a.Bt, gc_ = (gptr_d)a.ct;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) { fp[r] = gc_; fstr[r] = 0; fc[r] = 0.0; fld[r] = false; }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = rg + 4 * r;
-            double v = 0.0;
             if (row < NR) {
-                if (col < NR) v = At[row * NR + col];
-                else if (col < NS) v = KIND == KIND_REL_M ? Bt[row * M + (col - NR)] : 0.0;
-                else if (col == NS) v = a.ct[(size_t)t * NR + row];
-                else if (col >= NHP && col < NHP + M) v = Bt[row * M + (col - NHP)];
+                if (col < NR) { fp[r] = gA + row * NR + col; fstr[r] = NR * NR; fld[r] = true; }
+                else if (col < NS) {
+                    if (KIND == KIND_REL_M) { fp[r] = gB + row * M + (col - NR); fstr[r] = NR * M; fld[r] = true; }
+                } else if (col == NS) { fp[r] = gc_ + row; fstr[r] = NR; fld[r] = true; }
+                else if (col >= NHP && col < NHP + M) { fp[r] = gB + row * M + (col - NHP); fstr[r] = NR * M; fld[r] = true; }
             } else if (row < NS) {
-                if (KIND == KIND_REL_M && col == row) v = 1.0;
-                else if (col == NHP + (row - NR)) v = 1.0;
+                if (KIND == KIND_REL_M && col == row) fc[r] = 1.0;
+                else if (col == NHP + (row - NR)) fc[r] = 1.0;
             } else if (row == NS && col == NS) {
-                v = 1.0;
+                fc[r] = 1.0;
             }
-            F[r] = v;
         }
         // A-operand of B~: lane (i = col, k = rg) holds B~[i][k]
-        Ba = 0.0;
         if (rg < M) {
-            if (col < NR) Ba = Bt[col * M + rg];
-            else if (col < NS) Ba = (col - NR) == rg ? 1.0 : 0.0;
+            if (col < NR) { fp[4] = gB + col * M + rg; fstr[4] = NR * M; fld[4] = true; }
+            else if (col < NS) fc[4] = (col - NR) == rg ? 1.0 : 0.0;
         }
+    }
+    // raw loads now, selection (load or constant) at the point of use: the waits for the prefetched values
+    // then sit where the NEXT step consumes them, not behind the loads
+    auto load_F = [&](int t, double* v) {
+#pragma unroll
+        for (int r = 0; r < 5; ++r) v[r] = fp[r][(long)t * fstr[r]];
     };
+    auto finish_F = [&](const double* v, v4d& F, double& Ba) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) F[r] = fld[r] ? v[r] : fc[r];
+        Ba = fld[4] ? v[4] : fc[4];
+    };
+    // the -Qs sd_t entries of the stage-cost tile: element (row < NR, col NS) and its mirror
+    int qidx[KA];
+    bool qhas[KA];
+#pragma unroll
+    for (int r = 0; r < KA; ++r) {
+        const int row = rg + 4 * r;
+        qhas[r] = (col == NS && row < NR) || (row == NS && col < NR);
+        qidx[r] = qhas[r] ? (col == NS ? row : col) : 0;
+    }
 
     int bad = 0;
     // ---- backward sweep t = t_hi .. t_lo (descending): policies for the pinned sets, cost-to-go, tiles ----
@@ -243,27 +366,35 @@ __global__ __launch_bounds__(64) void ctrlbox_mfma_kernel(BoxArgs a, double* gws
 #pragma unroll
             for (int r = 0; r < KA; ++r) P[r] = Pt[(size_t)(t_hi + 1) * L::PT + (r * 4 + rg) * NHP + col];
         }
-        v4d Fn;
-        double Ban;
-        load_F(t_hi, Fn, Ban);
+        double Fraw[5];
+        double acn[M], lon[M], hin[M], qn[KA];
+        auto load_step = [&](int t) {
+            load_F(t, Fraw);
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                acn[j] = act_[(size_t)t * M + j];
+                lon[j] = lo_[(size_t)t * M + j];
+                hin[j] = hi_[(size_t)t * M + j];
+            }
+#pragma unroll
+            for (int r = 0; r < KA; ++r) qn[r] = qsd[(size_t)t * NR + qidx[r]];
+        };
+        load_step(t_hi);
         for (int t = t_hi; t >= t_lo; --t) {
-            const v4d F = Fn;
-            const double Ba = Ban;
-            if (t > t_lo) load_F(t - 1, Fn, Ban);            // prefetch
-            // active set and pinned values of this step (wave-uniform reads)
+            v4d F;
+            double Ba;
+            finish_F(Fraw, F, Ba);
+            // active set and pinned values of this step (wave-uniform)
             double ac[M], bb[M];
 #pragma unroll
             for (int j = 0; j < M; ++j) {
-                ac[j] = act_[(size_t)t * M + j];
-                bb[j] = ac[j] < 0.0 ? lo_[(size_t)t * M + j] : hi_[(size_t)t * M + j];
+                ac[j] = acn[j];
+                bb[j] = acn[j] < 0.0 ? lon[j] : hin[j];
             }
             v4d Lt = Lc;
 #pragma unroll
-            for (int r = 0; r < KA; ++r) {
-                const int row = rg + 4 * r;
-                if (col == NS && row < NR) Lt[r] = -qsd[(size_t)t * NR + row];
-                else if (row == NS && col < NR) Lt[r] = -qsd[(size_t)t * NR + col];
-            }
+            for (int r = 0; r < KA; ++r) Lt[r] = qhas[r] ? -qn[r] : Lc[r];
+            if (t > t_lo) load_step(t - 1);                   // prefetch
             // D1 = P~ F ;  Theta = L_t + F' D1
             v4d D1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -271,45 +402,50 @@ __global__ __launch_bounds__(64) void ctrlbox_mfma_kernel(BoxArgs a, double* gws
             v4d Th = Lt;
 #pragma unroll
             for (int s = 0; s < KA; ++s) Th = __builtin_amdgcn_mfma_f64_16x16x4f64(F[s], D1[s], Th, 0, 0, 0);
-            // H = Theta_nu,nu to every lane; this lane's column of Theta_nu,: (rows NHP + i sit in register RN
-            // of lanes 16 i + col)
-            double H[M][M], gc[M];
+            // H = Theta_nu,nu to every lane (symmetric: 10 of 16 by readlane); this lane's column of
+            // Theta_nu,: (rows NHP + i sit in register RN of lanes 16 i + col).
+            // The active set enters as 0/1 factors mf_i (free) -- products instead of per-element selects: a
+            // lone wave pays ~5 cycles for EVERY instruction, and the step is instruction-bound.
+            double H[M][M], gc[M], mf[M], bz[M];
 #pragma unroll
             for (int i = 0; i < M; ++i) {
 #pragma unroll
-                for (int j = 0; j < M; ++j) H[i][j] = readlane_d(Th[RN], 16 * i + NHP + j);
+                for (int j = i; j < M; ++j) {
+                    H[i][j] = readlane_d(Th[RN], 16 * i + NHP + j);
+                    H[j][i] = H[i][j];
+                }
                 gc[i] = __shfl(Th[RN], 16 * i + col, 64);
+                mf[i] = ac[i] == 0.0 ? 1.0 : 0.0;
+                bz[i] = ac[i] == 0.0 ? 0.0 : bb[i];          // pinned value, 0 for a free component
             }
-            // masked system: free rows/columns of H, identity on the pinned ones
+            // masked LDL': free rows/columns of H, identity on the pinned ones
             double Lm[M][M], Dg[M], Dinv[M], y[M];
 #pragma unroll
             for (int j = 0; j < M; ++j) {
-                const bool fj = ac[j] == 0.0;
-                double dj = fj ? H[j][j] : 1.0;
+                double dj = H[j][j];
 #pragma unroll
                 for (int l = 0; l < j; ++l) dj -= Lm[j][l] * Lm[j][l] * Dg[l];
+                dj = ac[j] == 0.0 ? dj : 1.0;
                 if (!(dj > 0.0) && bad == 0) bad = t + 1;
                 Dg[j] = dj;
                 Dinv[j] = fast_rcp_m(dj);
+                const double sj = Dinv[j] * mf[j];
 #pragma unroll
                 for (int i = j + 1; i < M; ++i) {
-                    double s = (fj && ac[i] == 0.0) ? H[i][j] : 0.0;
+                    double s = H[i][j];
 #pragma unroll
                     for (int l = 0; l < j; ++l) s -= Lm[i][l] * Lm[j][l] * Dg[l];
-                    Lm[i][j] = s * Dinv[j];
+                    Lm[i][j] = s * sj * mf[i];               // zero when i or j is pinned
                 }
             }
+            const double hsel = col == NS ? 1.0 : 0.0;
 #pragma unroll
             for (int i = 0; i < M; ++i) {
                 // right-hand side of the free rows: Theta_f,col + (homogeneous column) sum_p H_fp b_p
-                double s = 0.0;
-                if (ac[i] == 0.0) {
-                    s = gc[i];
-                    if (col == NS) {
+                double hb = 0.0;
 #pragma unroll
-                        for (int l = 0; l < M; ++l) s += ac[l] != 0.0 ? H[i][l] * bb[l] : 0.0;
-                    }
-                }
+                for (int l = 0; l < M; ++l) hb = fma(H[i][l], bz[l], hb);
+                double s = (gc[i] + hsel * hb) * mf[i];
 #pragma unroll
                 for (int l = 0; l < i; ++l) s -= Lm[i][l] * y[l];
                 y[i] = s;
@@ -321,15 +457,16 @@ __global__ __launch_bounds__(64) void ctrlbox_mfma_kernel(BoxArgs a, double* gws
                 for (int l = i + 1; l < M; ++l) s -= Lm[l][i] * y[l];
                 y[i] = s;
             }
-            // K~[rg][col] in B-operand layout (= K~' in A-operand layout)
-            double Kb = 0.0;
-            bool my_free = false;
+            // K~[rg][col] in B-operand layout (= K~' in A-operand layout): free rows -y, pinned rows b e_h'
+            // (y = 0 on a pinned row, bz = 0 on a free one)
+            double Kb = 0.0, mfree = 0.0;
 #pragma unroll
             for (int i = 0; i < M; ++i) {
-                const double kv = ac[i] == 0.0 ? -y[i] : (col == NS ? bb[i] : 0.0);
-                if (i == rg) { Kb = kv; my_free = ac[i] == 0.0; }
+                const double kv = hsel * bz[i] - y[i];
+                if (i == rg) { Kb = kv; mfree = mf[i]; }
             }
             if (rg >= M || col >= NH) Kb = 0.0;
+            const bool my_free = mfree != 0.0;
             // D = Theta + Theta[:, nu] K~ ;  P~ = D + K~' Y, Y = rows of nu of D
             v4d D = __builtin_amdgcn_mfma_f64_16x16x4f64(Th[RN], Kb, Th, 0, 0, 0);
             v4d Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(Kb, D[RN], D, 0, 0, 0);
@@ -367,21 +504,25 @@ __global__ __launch_bounds__(64) void ctrlbox_mfma_kernel(BoxArgs a, double* gws
             }
         }
         double g[KA], gn[KA];
-        double acn = 0.0, bdn = 0.0;
-        auto fetch = [&](int t, double* gg, double& acx, double& bdx) {
+        double acn = 0.0, lon = 0.0, hin = 0.0;
+        const int jj = rg < M ? rg : 0;
+        const int gofs = col < L::GR ? col : 0;
+        auto fetch = [&](int t, double* gg, double& acx, double& lox, double& hix) {
             const double* G = Gt + (size_t)t * L::GT;
 #pragma unroll
-            for (int s = 0; s < KA; ++s) gg[s] = col < L::GR ? G[(4 * s + rg) * L::GR + col] : 0.0;
-            const int j = rg < M ? rg : 0;
-            acx = act_[(size_t)t * M + j];
-            bdx = acx < 0.0 ? lo_[(size_t)t * M + j] : hi_[(size_t)t * M + j];
+            for (int s = 0; s < KA; ++s) gg[s] = G[(4 * s + rg) * L::GR + gofs];
+            acx = act_[(size_t)t * M + jj];
+            lox = lo_[(size_t)t * M + jj];
+            hix = hi_[(size_t)t * M + jj];
         };
-        fetch(t0, gn, acn, bdn);
+        fetch(t0, gn, acn, lon, hin);
         for (int t = t0; t < T; ++t) {
 #pragma unroll
             for (int s = 0; s < KA; ++s) g[s] = gn[s];
-            const double acx = acn, bdx = bdn;
-            if (t + 1 < T) fetch(t + 1, gn, acn, bdn);
+#pragma unroll
+            for (int s = 0; s < KA; ++s) g[s] = col < L::GR ? g[s] : 0.0;
+            const double acx = acn, bdx = acn < 0.0 ? lon : hin;
+            if (t + 1 < T) fetch(t + 1, gn, acn, lon, hin);
             v4d Dn = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int s = 0; s < KA; ++s) Dn = __builtin_amdgcn_mfma_f64_16x16x4f64(g[s], S[s], Dn, 0, 0, 0);
@@ -396,49 +537,78 @@ __global__ __launch_bounds__(64) void ctrlbox_mfma_kernel(BoxArgs a, double* gws
         rsync();
     };
 
-    // ---- MPC loop --------------------------------------------------------------------
-    double xr[NR], ur[M], xn[NR], up[M];
+    // ---- cold start of the first tail: the SATURATED unconstrained policy.  With every component free the
+    // sweep above is the plain Riccati pass; rolling its policy out on the linear model with the controls
+    // clipped to their boxes (s~+ = A~cl s~ + B~ (clip(nu) - nu)) pins what that rollout saturates -- most of
+    // the set the QP's solution binds.  From there the active-set iterations of the benchmark's first tail
+    // sweep ~230 time steps instead of ~1090 (oracle twin: local_descent_quasistatic_as, sat_start).  The
+    // starting set does not change the answer (strictly convex QP); once per descent, T steps.
+    auto saturated_start = [&](int t0) {
+        v4d S = {0.0, 0.0, 0.0, 0.0};
+        if (col == 0) {
 #pragma unroll
-    for (int i = 0; i < NR; ++i) xr[i] = a.x0[i];
+            for (int s = 0; s < KA; ++s) {
+                const int k = rg + 4 * s;
+                S[s] = k < NH ? sstart[k] : 0.0;
+            }
+        }
+        const gptr_d gB = (gptr_d)a.Bt;
+        for (int t = t0; t < T; ++t) {
+            const double* G = Gt + (size_t)t * L::GT;
+            v4d Dn = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int j = 0; j < M; ++j) up[j] = 0.0;
-    if (lane == 0) {
+            for (int s = 0; s < KA; ++s) {
+                const double g = col < L::GR ? G[(4 * s + rg) * L::GR + (col < L::GR ? col : 0)] : 0.0;
+                Dn = __builtin_amdgcn_mfma_f64_16x16x4f64(g, S[s], Dn, 0, 0, 0);
+            }
+            // unclipped controls sit in register RN of lanes 16 j: clip, record the pin, broadcast the excess
+            double dlt[M];
 #pragma unroll
-        for (int i = 0; i < NR; ++i) a.x_new[i] = xr[i];
-    }
-    auto quad = [&](const double* Wq, const double* e, int Kd) -> double {
-        double s = 0.0;
-        for (int i = 0; i < Kd; ++i)
-            for (int j = 0; j < Kd; ++j) s += e[i] * Wq[i * Kd + j] * e[j];
-        return s;
+            for (int j = 0; j < M; ++j) {
+                const double v = readlane_d(Dn[RN], 16 * j);
+                const double lo = lo_[(size_t)t * M + j], hi = hi_[(size_t)t * M + j];
+                const double c = fmin(fmax(v, lo), hi);
+                dlt[j] = c - v;
+                if (lane == 0) act_[(size_t)t * M + j] = v < lo - tol_ ? -1.0 : (v > hi + tol_ ? 1.0 : 0.0);
+            }
+            // s~+ rows (column 0): x rows += B delta, w rows += delta
+            if (col == 0) {
+#pragma unroll
+                for (int s = 0; s < KA; ++s) {
+                    const int row = rg + 4 * s;
+                    double corr = 0.0;
+                    if (row < NR) {
+#pragma unroll
+                        for (int j = 0; j < M; ++j) corr += gB[((size_t)t * NR + row) * M + j] * dlt[j];
+                    } else if (row < NS) {
+#pragma unroll
+                        for (int j = 0; j < M; ++j) corr = (row - NR == j) ? dlt[j] : corr;
+                    }
+                    S[s] = Dn[s] + corr;
+                }
+            }
+        }
+        rsync();
     };
-    double cost = 0.0;
+
+    // ---- MPC loop (solver side) ----------------------------------------------------------
     int it_max = 0, n_fail = 0;
     const double tol = a.eps;
     bool full = true;                                  // no valid backward sweep yet
+    wg_barrier();                                      // S0: tables and records are up
 
     for (int tau = 0; tau < T; ++tau) {
-        // start state [x; x[idx]]: each tail's first du is measured from the realised actuated
-        // position (tv_lqr.py:99-100 at the tail's local t = 0)
-        double ub[M];
-#pragma unroll
-        for (int j = 0; j < M; ++j) {
-            double v = xr[0];
-#pragma unroll
-            for (int i = 1; i < NR; ++i) v = (i == Model::u_into_x(j)) ? xr[i] : v;
-            ub[j] = v;
-        }
-        if (lane < NH) {
-            double v = xr[0];
-#pragma unroll
-            for (int i = 1; i < NR; ++i) v = (i == lane) ? xr[i] : v;
-#pragma unroll
-            for (int j = 0; j < M; ++j) v = (NR + j == lane) ? ub[j] : v;
-            sstart[lane] = lane == NS ? 1.0 : v;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
+        wg_barrier();                                  // A(tau): the plant has published this tail's start state
         const int t0 = tau;
+        if (tau == 0) {
+            // no warm start handed in (act_io absent or all zero): start from the saturated policy
+            bool any = false;
+            for (int q = lane; q < T * M; q += 64) any = any || act_[q] != 0.0;
+            if (!__any(any)) {
+                backward_sweep(T - 1, 0);
+                saturated_start(0);
+            }
+        }
         int t_dirty = full ? T - 1 : t0 - 1;           // the sweep of the previous tail covers t >= tau
         int iters = 0;
         bool conv = false;
@@ -539,43 +709,15 @@ __global__ __launch_bounds__(64) void ctrlbox_mfma_kernel(BoxArgs a, double* gws
         if (tau == 0 && a.act_io != nullptr) {
             for (int q = lane; q < T * M; q += 64) a.act_io[q] = act_[q];
         }
-        // first control of the tail solution (clipped), true dynamics step
-#pragma unroll
-        for (int j = 0; j < M; ++j) {
-            const size_t q = (size_t)tau * M + j;
-            const double v = fmin(fmax(uu_[q], lo_[q]), hi_[q]);
-            ur[j] = KIND == KIND_ABS_M ? v : ub[j] + v;
+        // first control of the tail solution (clipped) -> the plant
+        if (lane < M) {
+            const size_t q = (size_t)tau * M + lane;
+            uctl[lane] = fmin(fmax(uu_[q], lo_[q]), hi_[q]);
         }
-        {   // IrsLqrQuasistatic.eval_cost (irs_lqr_quasistatic.py:153-194)
-            double e[NR], dv[M];
-#pragma unroll
-            for (int i = 0; i < NR; ++i) e[i] = xr[i] - a.xd[(size_t)tau * NR + i];
-#pragma unroll
-            for (int j = 0; j < M; ++j) dv[j] = ur[j] - (tau == 0 ? ub[j] : up[j]);
-            cost += quad(Qsym, e, NR) + quad(Rsym, dv, M);
-        }
-        true_step_m<Model>(a.p, xr, ur, xn);
-#pragma unroll
-        for (int i = 0; i < NR; ++i) xr[i] = xn[i];
-#pragma unroll
-        for (int j = 0; j < M; ++j) up[j] = ur[j];
-        if (lane == 0) {
-#pragma unroll
-            for (int j = 0; j < M; ++j) a.u_new[(size_t)tau * M + j] = ur[j];
-#pragma unroll
-            for (int i = 0; i < NR; ++i) a.x_new[(size_t)(tau + 1) * NR + i] = xr[i];
-        }
-        rsync();
-    }
-    {
-        double e[NR];
-#pragma unroll
-        for (int i = 0; i < NR; ++i) e[i] = xr[i] - a.xd[(size_t)T * NR + i];
-        cost += quad(Qdsym, e, NR);
+        wg_barrier();                                  // B(tau)
     }
     if (lane == 0) {
         a.info[0] = bad; a.info[1] = it_max; a.info[2] = n_fail;
-        if (a.cost) a.cost[0] = cost;
     }
 }
 
@@ -600,10 +742,10 @@ int launch_ctrlbox_mfma(const BoxArgs& a, double* ws, size_t ws_bytes, hipStream
             irs_set_error("irs_quasistatic_box_descent: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return IRS_ERR_HIP;
         }
-        hipLaunchKernelGGL(kern, dim3(1), dim3(64), bytes, st, a, (double*)nullptr);
+        hipLaunchKernelGGL(kern, dim3(1), dim3(128), bytes, st, a, (double*)nullptr);
     } else {
         auto kern = ctrlbox_mfma_kernel<Model, KIND, false>;
-        hipLaunchKernelGGL(kern, dim3(1), dim3(64), bytes, st, a, ws);
+        hipLaunchKernelGGL(kern, dim3(1), dim3(128), bytes, st, a, ws);
     }
     return IRS_OK;
 }

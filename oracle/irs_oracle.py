@@ -1627,13 +1627,30 @@ def ctrlbox_workspace(prob):
     return W
 
 
+def ctrlbox_saturated_start(prob, s_start, lo, hi, act, W, tol=1e-10):
+    """Cold start of the first tail (csrc/ctrlbox_mfma.hip, saturated_start): sweep with every component free
+    (the plain Riccati pass), then roll that policy out on the linear model with the controls CLIPPED to their
+    boxes and pin what the rollout saturates.  Returns the number of time steps swept.  The starting set does
+    not change the QP's solution, only how many sweeps the active-set iterations need to reach it."""
+    T = prob["B"].shape[0]
+    act[:] = 0
+    ctrlbox_backward(prob, act, lo, hi, T - 1, 0, W)
+    s = np.array(s_start, dtype=float)
+    for t in range(T):
+        v = W["K"][t] @ s + W["k"][t]
+        act[t] = np.where(v < lo[t] - tol, -1, np.where(v > hi[t] + tol, 1, 0))
+        s = prob["A"][t] @ s + prob["B"][t] @ np.clip(v, lo[t], hi[t]) + prob["c"][t]
+    return T
+
+
 def local_descent_quasistatic_as(system, At, Bt, ct, Q, Qd, R, x0, xd_trj, lo, hi, kind, pdas_iter=10,
-                                 max_iter=2000, tol=1e-10, act_io=None):
+                                 max_iter=2000, tol=1e-10, act_io=None, sat_start=False):
     """irs_lqr_quasistatic.py:326-345 with ONE control box (kind "abs": lo,hi (T,m) absolute rows
     on u_t; kind "rel": rows on u_t - u_{t-1}): T tail QPs solved EXACTLY by the active-set method,
     the active set and the backward pass carried from tail to tail.  `act_io` (T,m) in {-1,0,+1}, in/out
     (include/irs_hip.h, irs_quasistatic_box_descent_ws): the set the first tail starts from (a previous
-    iteration's) and, on return, the set it converged to."""
+    iteration's) and, on return, the set it converged to.  `sat_start`: without a warm start, the first tail
+    starts from the saturated unconstrained policy (ctrlbox_saturated_start; the matrix-core kernel does)."""
     T, n, m = Bt.shape
     idx = system.indices_u_into_x
     prob = quasistatic_ctrl_problem(At, Bt, ct, Q, Qd, R, xd_trj, kind)
@@ -1648,8 +1665,12 @@ def local_descent_quasistatic_as(system, At, Bt, ct, Q, Qd, R, x0, xd_trj, lo, h
     u = np.zeros((T, m))
     for t in range(T):
         s_t = np.concatenate([x_new[t], x_new[t][idx]])
+        extra = 0
+        if t == 0 and sat_start and not act.any():
+            extra = ctrlbox_saturated_start(prob, s_t, lo, hi, act, W, tol)
         s, u, mu, st, valid_from = ctrlbox_solve(prob, s_t, t, lo, hi, u, act, W, valid_from, pdas_iter,
                                                  max_iter, tol)
+        st = (st[0], st[1], st[2] + extra)
         stats.append(st)
         if t == 0 and act_io is not None:
             act_io[:] = act

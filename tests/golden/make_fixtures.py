@@ -268,6 +268,10 @@ def copy_box_pushing_data():
     for name in ("xu_quasistatic.npy", "dxdu_quasistatic.npy"):
         shutil.copyfile(os.path.join(src, name), os.path.join(HERE, "box_pushing_" + name))
         print("copied", "box_pushing_" + name)
+    # the reference's own result file of run_box_pushing.py with gradient_mode "exact": 22 costs, converged to
+    # 112.0110165024113 = 50 (3 0.5^2 + 3 0.5^2 + 1.2 (pi/4)^2) -- the box never moves (a result file: data)
+    shutil.copyfile(os.path.join(src, "box_pushing_exact.csv"), os.path.join(HERE, "box_pushing_exact.csv"))
+    print("copied box_pushing_exact.csv")
 
 
 if __name__ == "__main__":

@@ -586,6 +586,66 @@ def test_box_pushing_step_reproduces_simulator_trajectory(golden_dir):
     np.testing.assert_allclose(xr, x, rtol=0, atol=2e-7)
 
 
+def _box_pushing_script_problem(T):
+    """examples/box_pushing/run_box_pushing.py:20-131 (x = [x_h, x_b, y_h, y_b, th_b])."""
+    BOX = orc.BoxPivotOracle
+    q_u0, qa0 = np.array([0.0, 0.5, 0.0]), np.array([0.0, -0.2])
+    x0 = BOX.pack(q_u0, qa0)
+    Q = np.diag(BOX.pack([3.0, 3.0, 1.2], [0.0, 0.0]))                 # :101-103
+    Qd = 0.0 * Q                                                      # :104
+    R = 1e1 * np.eye(2)                                               # :105
+    xd = np.tile(BOX.pack(q_u0 + np.array([0.5, 0.5, -np.pi / 4]), qa0), (T + 1, 1))     # :107-110
+    return x0, np.tile(qa0, (T, 1)), Q, Qd, R, xd
+
+
+def test_box_pushing_exact_csv_pins_cost_bookkeeping_and_exact_mode(golden_dir):
+    """The reference's result file examples/box_pushing/analysis/box_pushing_exact.csv (run_box_pushing.py,
+    gradient_mode "exact"): from its third entry on, 112.0110165024113, twenty times over.  That number is
+    50 (3 0.5^2 + 3 0.5^2 + 1.2 (pi/4)^2) to 1.5e-11: the box at rest for T = 50 steps (the script in the tree says
+    T = 60: it has drifted from the file), running rows weighted by Q_dict, NO terminal row (Qd = 0 Q,
+    :104), zero input-rate cost.  It pins (1) IrsLqrQuasistatic.eval_cost's bookkeeping
+    (irs_lqr_quasistatic.py:153-194): T running rows 0..T-1, the terminal row with Qd, du measured from
+    x_0[idx]; (2) the behaviour of gradient_mode "exact" out of contact: the hand (0.1 from the box) sees a
+    zero derivative of the box with respect to its command, so the bounded QP's optimum is "do not move" and
+    the cost stays put -- iteration after iteration, as in the file.  Its first two entries (112.0360...,
+    112.0167...) come from an initial hand motion the scripts in the tree no longer contain (10 |du|^2 =
+    0.025): not reproducible."""
+    gold = np.loadtxt(os.path.join(golden_dir, "box_pushing_exact.csv"))
+    assert len(gold) == 22 and np.ptp(gold[3:]) == 0.0
+    T = 50
+    x0, u0, Q, Qd, R, xd = _box_pushing_script_problem(T)
+    o = orc.BoxPushOracle(0.1)
+    idx = o.indices_u_into_x
+    x_trj = orc.rollout(o, x0, u0)
+    assert np.abs(x_trj - x0).max() == 0.0                                   # nothing moves
+    closed_form = 50 * (3 * 0.25 + 3 * 0.25 + 1.2 * (np.pi / 4) ** 2)
+    c = orc.eval_cost_quasistatic(x_trj, u0, xd, Q, Qd, R, idx)
+    np.testing.assert_allclose(c, closed_form, rtol=1e-15)
+    # (the file sits 1.5e-11 below the closed form: the simulator's interior-point QP leaves the resting
+    # box a hair off its pose)
+    np.testing.assert_allclose(gold[2:], c, rtol=1e-10)
+    # T = 60 (the script as it stands) or a terminal row would NOT give the file's number
+    x60 = orc.rollout(o, x0, np.tile(u0[0], (60, 1)))
+    assert abs(orc.eval_cost_quasistatic(x60, np.tile(u0[0], (60, 1)), np.tile(xd[0], (61, 1)), Q, Qd, R, idx) - gold[-1]) > 20
+    assert abs(orc.eval_cost_quasistatic(x_trj, u0, xd, Q, Q, R, idx) - gold[-1]) > 2
+    # the host twin's eval_cost (five terms, per-model dicts) gives the same number
+    import types
+    from irs_mpc_amd.quasistatic_base import quasistatic_eval_cost
+    qd = types.SimpleNamespace(position_indices={"box": np.array([1, 3, 4]), "hand": np.array([0, 2])},
+                               models_unactuated=["box"], models_actuated=["hand"],
+                               get_u_indices_into_x=lambda: np.array([0, 2]))
+    terms = quasistatic_eval_cost(qd, x_trj, u0, xd, {"box": np.array([3.0, 3.0, 1.2]), "hand": np.zeros(2)},
+                                  {"box": np.zeros(3), "hand": np.zeros(2)}, R)
+    np.testing.assert_allclose(sum(terms), c, rtol=1e-15)
+    # gradient_mode "exact" + the script's rate bound: the descent keeps the hand where it is
+    At, Bt, ct = orc.exact_contact_TV(o, x_trj, u0, decouple=True)
+    assert np.abs(Bt[:, [1, 3, 4], :]).max() == 0.0                          # no contact: the box does not see u
+    lo, hi = np.full((T, 2), -0.04), np.full((T, 2), 0.04)                   # :117-118: +-0.4 h
+    xa, ua, _ = orc.local_descent_quasistatic_as(o, At, Bt, ct, Q, Qd, R, x0, xd, lo, hi, "rel")
+    np.testing.assert_allclose(orc.eval_cost_quasistatic(xa, ua, xd, Q, Qd, R, idx), c, rtol=1e-13)
+    np.testing.assert_allclose(orc.eval_cost_quasistatic(xa, ua, xd, Q, Qd, R, idx), gold[-1], rtol=1e-10)
+
+
 def test_box_pushing_active_set_jacobian_matches_simulator(golden_dir):
     """PIN of the contact step's DERIVATIVE (gradient modes "exact" / "first_order"): the analytic
     active-set Jacobian of the restated step against all 80 of the simulator's own
@@ -671,3 +731,28 @@ def test_box_pushing_input_jacobian_matches_simulator(golden_dir):
         np.testing.assert_allclose(Jf[:, 5:], J[t][:, 5:], rtol=0, atol=1.5e-3)       # B, all rows
         np.testing.assert_allclose(Jf[[2, 3]], J[t][[2, 3]], rtol=0, atol=1e-4)        # y rows of [A | B]
     assert abs(J[40][4, 5] - 1.5799) < 1e-3 and abs(J[40][2, 6] - 0.5) < 1e-6          # the data really are in contact
+
+
+def test_saturated_start_same_solution_fewer_sweeps():
+    """The cold start of the matrix-core descent kernel (saturated unconstrained policy) restated: the T
+    re-solved tail QPs have the same solutions from either starting set, and the benchmark-like problem
+    (planar hand, trust region binding on about half the components) needs fewer backward time steps."""
+    T = 30
+    o = orc.PlanarHandOracle(0.1)
+    idx = o.indices_u_into_x
+    x0 = _hand_x0()
+    u_trj = np.tile(x0[idx], (T, 1))
+    x_trj = orc.rollout(o, x0, u_trj)
+    du = 0.3 * np.random.default_rng(3).normal(size=(T, 300, 4))
+    At, Bt, ct = orc.zero_order_B_decoupled(o, x_trj, u_trj, du)
+    q = orc.PlanarHandOracle.pack([1e-3, 1e-3, 10.0], [1e-3, 1e-3], [1e-3, 1e-3])
+    Q, Qd, R = np.diag(q), np.diag(100 * q), 5.0 * np.eye(4)
+    xd = np.tile(x0 + orc.PlanarHandOracle.pack([0.3, -0.1, 0.5], [0, 0], [0, 0]), (T + 1, 1))
+    for kind, (lo, hi) in (("abs", (x_trj[:-1, idx] - 0.05, x_trj[:-1, idx] + 0.05)),
+                           ("rel", (np.full((T, 4), -0.03), np.full((T, 4), 0.03)))):
+        xa, ua, st_a = orc.local_descent_quasistatic_as(o, At, Bt, ct, Q, Qd, R, x0, xd, lo, hi, kind)
+        xb, ub, st_b = orc.local_descent_quasistatic_as(o, At, Bt, ct, Q, Qd, R, x0, xd, lo, hi, kind, sat_start=True)
+        np.testing.assert_allclose(ub, ua, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(xb, xa, rtol=0, atol=1e-9)
+        if kind == "abs":
+            assert sum(s[2] for s in st_b) < 0.8 * sum(s[2] for s in st_a)
