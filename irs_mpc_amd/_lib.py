@@ -9,7 +9,8 @@ from ctypes import (POINTER, c_char_p, c_double, c_int, c_longlong, c_size_t,
                     c_uint32, c_uint64, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libirs_hip.so")
+# (IRS_HIP_LIB: a diagnostic build of the same library, e.g. tools/stamp_descent.sh)
+LIB_PATH = os.environ.get("IRS_HIP_LIB") or os.path.join(_HERE, "csrc", "libirs_hip.so")
 
 IRS_OK = 0
 MODEL_PENDULUM = 0

@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(ModelParams p, int T, 
     for (int i = 0; i < n; ++i) x[i] = x0[i];
     const double* ub = u_cand + (size_t)b * T * m;
     double cost = 0.0;
+    unsigned warm_set = ~0u;          // active set of the previous contact step (exact step QPs only)
     for (int t = 0; t <= T; ++t) {
         // (x_t - xd_t)' Q (x_t - xd_t); the terminal term also uses Q (cem.py:138-139)
         const double* xd = xd_trj + (size_t)t * n;      // uniform address: scalar loads
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(ModelParams p, int T, 
             for (int j = 0; j < m; ++j) r += Rs[i * m + j] * u[j];
             cost += u[i] * r;
         }
-        Model::template step<double>(p, x, u, xn);
+        irs_step_along<Model>(p, x, u, xn, &warm_set);
 #pragma unroll
         for (int i = 0; i < n; ++i) x[i] = xn[i];
     }
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(64) void cem_rollout_quasistatic_kernel(ModelParams
     for (int j = 0; j < m; ++j) up[j] = x0[Model::u_into_x(j)];
     const double* ub = u_cand + (size_t)b * T * m;
     double cost = 0.0;
+    unsigned warm_set = ~0u;          // active set of the previous contact step (exact step QPs only)
     for (int t = 0; t <= T; ++t) {
         const double* xd = xd_trj + (size_t)t * n;
         const double* W = t == T ? Qds : Qs;
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(64) void cem_rollout_quasistatic_kernel(ModelParams
             for (int j = 0; j < m; ++j) r += Rs[i * m + j] * dv[j];
             cost += dv[i] * r;
         }
-        Model::template step<double>(p, x, u, xn);
+        irs_step_along<Model>(p, x, u, xn, &warm_set);
 #pragma unroll
         for (int i = 0; i < n; ++i) x[i] = xn[i];
     }

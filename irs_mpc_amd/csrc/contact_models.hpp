@@ -231,9 +231,13 @@ IRS_HD bool irs_wave_all(bool v) {
 #endif
 }
 
+// `warm` (optional, in/out): bit i = row i of the active set.  In: a guess that REPLACES the warm-up sweeps
+// (~0u = none: sweep) -- consecutive steps of one trajectory bind nearly the same contacts, and a one-lane
+// f64 step is a latency chain in which the 32 sweeps are 2/3 of the time; out: the set the solve ended on.
+// The guess only shortens the path: the primal solution is unique.
 template <typename T, int NX, int NC>
 IRS_HD void irs_contact_qp_dual_exact(const T* Dinv, const T* b, const T (*J)[NX], const T* phi, T (*W)[NC],
-                                      T* lam) {
+                                      T* lam, unsigned* warm = nullptr) {
     constexpr T kBig = T(3.0e38);
     const T tol_rel = sizeof(T) == 4 ? T(1e-6) : T(1e-10);
     const T piv_rel = sizeof(T) == 4 ? T(1e-5) : T(1e-7);
@@ -277,19 +281,25 @@ IRS_HD void irs_contact_qp_dual_exact(const T* Dinv, const T* b, const T (*J)[NX
         T r[NC], invw[NC];
 #pragma unroll
         for (int i = 0; i < NC; ++i) { r[i] = g[i]; invw[i] = T(kContactPgsOmega) * irs_rcp_fast(Wd[i]); }
+        const bool guessed = warm != nullptr && *warm != ~0u;
+        if (guessed) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) act[i] = ((*warm >> i) & 1u) != 0u;
+        } else {
 #pragma unroll 2
-        for (int sw = 0; sw < kContactExactWarmSweeps; ++sw) {
+            for (int sw = 0; sw < kContactExactWarmSweeps; ++sw) {
 #pragma unroll
-            for (int i = 0; i < NC; ++i) {
-                const T nw = fmax(lam[i] - g[i] * invw[i], T(0));
-                const T dl = nw - lam[i];
-                lam[i] = nw;
+                for (int i = 0; i < NC; ++i) {
+                    const T nw = fmax(lam[i] - g[i] * invw[i], T(0));
+                    const T dl = nw - lam[i];
+                    lam[i] = nw;
 #pragma unroll
-                for (int j = 0; j < NC; ++j) g[j] = g[j] + W[j][i] * dl;
+                    for (int j = 0; j < NC; ++j) g[j] = g[j] + W[j][i] * dl;
+                }
             }
-        }
 #pragma unroll
-        for (int i = 0; i < NC; ++i) act[i] = lam[i] > T(0);
+            for (int i = 0; i < NC; ++i) act[i] = lam[i] > T(0);
+        }
         bool valid = false;
         for (int round = 0; round < 3; ++round) {
             if (irs_wave_all<T>(valid)) break;
@@ -451,6 +461,12 @@ IRS_HD void irs_contact_qp_dual_exact(const T* Dinv, const T* b, const T (*J)[NX
             if (full) p = -1;
         }
     }
+    if (warm != nullptr) {
+        unsigned mk = 0u;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) mk |= act[i] ? (1u << i) : 0u;
+        *warm = mk;
+    }
 }
 
 template <typename S, int NX, int NC>
@@ -572,7 +588,7 @@ struct irs_contact_exact<M, std::void_t<decltype(M::EXACT)>> : std::integral_con
 
 // One step of contact model M (its `assemble` builds the QP in the internal coordinate order).
 template <class M, typename S>
-IRS_HD void irs_contact_step(const ModelParams& p, const S* x_ext, const S* u, S* xn_ext) {
+IRS_HD void irs_contact_step(const ModelParams& p, const S* x_ext, const S* u, S* xn_ext, unsigned* warm = nullptr) {
     using T = typename scalar_of<S>::type;
     constexpr int NX = M::NX, NC = M::NC;
     S q[NX], qn[NX], b[NX], J[NC][NX], phi[NC];
@@ -580,7 +596,7 @@ IRS_HD void irs_contact_step(const ModelParams& p, const S* x_ext, const S* u, S
     const int iters = M::template assemble<S>(p, x_ext, u, q, Dinv, b, J, phi);
     if constexpr (irs_contact_exact<M>::value) {
         S W[NC][NC], lam[NC];
-        irs_contact_qp_dual_exact<S, NX, NC>(Dinv, b, J, phi, W, lam);
+        irs_contact_qp_dual_exact<S, NX, NC>(Dinv, b, J, phi, W, lam, warm);
         irs_contact_qp_primal<S, NX, NC>(q, Dinv, b, J, lam, qn);
     } else {
         irs_contact_qp_step<S, NX, NC>(q, Dinv, b, J, phi, iters, qn);
@@ -957,3 +973,11 @@ struct BoxPushExactModel : BoxPushModel {
         irs_contact_step<BoxPushExactModel, S>(p, x_ext, u, xn_ext);
     }
 };
+
+// One f64 step along a TRAJECTORY: models whose step QP is solved exactly take the previous step's active set
+// as the starting guess of this one (`warm`: ~0u before the first step); every other model just steps.
+template <class Model>
+IRS_HD void irs_step_along(const ModelParams& p, const double* x, const double* u, double* xn, unsigned* warm) {
+    if constexpr (irs_contact_exact<Model>::value) irs_contact_step<Model, double>(p, x, u, xn, warm);
+    else Model::template step<double>(p, x, u, xn);
+}

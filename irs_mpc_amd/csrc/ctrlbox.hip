@@ -23,7 +23,7 @@
 // Restated in oracle/irs_oracle.py (quasistatic_ctrl_problem / ctrlbox_backward / ctrlbox_solve /
 // local_descent_quasistatic_as), checked there against the ADMM solution of the same QPs.
 //
-// One wave, f64, everything in (dynamic) LDS: a latency-bound chain like the Riccati pass.
+// One solver wave (+ one plant wave), f64, everything in (dynamic) LDS: a latency-bound chain like the Riccati pass.
 #include "boxqp.hpp"
 
 namespace {
@@ -76,25 +76,26 @@ struct CbLayout {
                          oact = omu + M, olo = oact + M, ohi = olo + M, oqsd = ohi + M, S = oqsd + NR;
     static constexpr int NTRI = NS * (NS + 1) / 2;
     static constexpr int scratch = NS * NR + 2 * M * NS + 4 * NS + 2 * M * M + M * (NS + 1) + 2 * NR * NR +
-                                   NTRI + 64;
+                                   NTRI + M + 64;
     static __host__ __device__ size_t doubles(int T) { return (size_t)(T + 1) * S + scratch; }
 };
 
-// The f64 contact step needs hundreds of registers (the 8x8 / 12x12 dual Hessian); kept out of line so
-// that its allocation does not push the solver's hot loops into scratch.  Called once per tail.
-template <class Model>
-__device__ __noinline__ void true_step(const ModelParams& p, const double* x, const double* u, double* xn) {
-    Model::template step<double>(p, x, u, xn);
-}
-
+// Two waves, two roles (as in ctrlbox_mfma.hip, which has the story): wave 0 solves, wave 1 -- the PLANT --
+// owns the realised state, applies each tail's first control to the true (contact) dynamics, accumulates
+// eval_cost and publishes the next start state; two workgroup barriers per tail.  The contact step used to
+// be an out-of-line function called from the solver wave, and every value of the caller that was live
+// across that call was at the mercy of the register pressure around it (256 VGPRs + up to 256 AGPRs taken
+// by the callee): a wrong accumulated cost and an unwritten `info` were seen on the box-pivoting
+// instantiation.  As a separate wave there is no call and nothing live across the step.
 template <class Model, int KIND>
-__global__ __launch_bounds__(64) void ctrlbox_descent_kernel(BoxArgs a) {
+__global__ __launch_bounds__(128) void ctrlbox_descent_kernel(BoxArgs a) {
     constexpr int NR = Model::NX, M = Model::NU, NS = NR + M;
     constexpr double INF = __builtin_huge_val();
     static_assert(M * (NS + 1) <= 64 && M * NS + M <= 64, "one wave computes [K | k] in a single pass");
     using L = CbLayout<NR, M>;
     extern __shared__ double lds[];
-    const int T = a.T, lane = threadIdx.x;
+    const int T = a.T, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // 0 solver, 1 plant
     double* F = lds;
     double* PB = F + (size_t)(T + 1) * L::S;           // NS x M    P B_
     double* WA = PB + NS * M;                          // NS x NR   P[:, :NR] A
@@ -106,8 +107,9 @@ __global__ __launch_bounds__(64) void ctrlbox_descent_kernel(BoxArgs a) {
     double* Qsym = RHS + M * (NS + 1);                 // NR x NR
     double* Qdsym = Qsym + NR * NR;                    // NR x NR
     double* Rsym = Qdsym + NR * NR;                    // M x M
-    double* sstart = Rsym + M * M;                     // NS
-    int* tri = reinterpret_cast<int*>(sstart + NS);    // (i << 8 | j), i <= j, of the upper triangle
+    double* sstart = Rsym + M * M;                     // NS   (plant -> solver)
+    double* uctl = sstart + NS;                        // M: the tail's first control, clipped (solver -> plant)
+    int* tri = reinterpret_cast<int*>(uctl + M);       // (i << 8 | j), i <= j, of the upper triangle
 
     auto rec_ = [&](int t) -> double* { return F + (size_t)t * L::S; };
     // problem data of the LQR in s = [x; w]
@@ -116,12 +118,93 @@ __global__ __launch_bounds__(64) void ctrlbox_descent_kernel(BoxArgs a) {
         if (KIND == KIND_ABS && i >= NR && j >= NR) return Rsym[(i - NR) * M + (j - NR)];
         return 0.0;
     };
-    // ---- setup ------------------------------------------------------------------------
+    auto wg_barrier = [&]() {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
     // sentinels: a launch that does not reach its epilogue must not leave a previous launch's values
     // behind (info = -1 is rejected by the host like any other failure; cost = NaN)
+    // ---- the plant wave: barriers S0 (tables up), then per tail A (start state ready), B (control ready) ----
+    if (wave == 1) {
+        double xr[NR], ur[M], xn[NR], up[M], ub[M];
+        if (lane == 0 && a.cost) a.cost[0] = __builtin_nan("");
+#pragma unroll
+        for (int i = 0; i < NR; ++i) xr[i] = a.x0[i];
+#pragma unroll
+        for (int j = 0; j < M; ++j) up[j] = 0.0;
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) a.x_new[i] = xr[i];
+        }
+        auto quad = [&](const double* Wq, const double* e, int Kd) -> double {
+            double q = 0.0;
+            for (int i = 0; i < Kd; ++i)
+                for (int j = 0; j < Kd; ++j) q += e[i] * Wq[i * Kd + j] * e[j];
+            return q;
+        };
+        // start state [x; x[idx]]: each tail's first du is measured from the realised actuated
+        // position (tv_lqr.py:99-100 at the tail's local t = 0)
+        auto publish_start = [&]() {
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                double v = xr[0];
+#pragma unroll
+                for (int i = 1; i < NR; ++i) v = (i == Model::u_into_x(j)) ? xr[i] : v;
+                ub[j] = v;
+            }
+            if (lane < NS) {
+                double v = xr[0];
+#pragma unroll
+                for (int i = 1; i < NR; ++i) v = (i == lane) ? xr[i] : v;
+#pragma unroll
+                for (int j = 0; j < M; ++j) v = (NR + j == lane) ? ub[j] : v;
+                sstart[lane] = v;
+            }
+        };
+        double cost = 0.0;
+        unsigned warm = ~0u;                                // active set of the previous contact step
+        wg_barrier();                                       // S0
+        publish_start();
+        for (int tau = 0; tau < T; ++tau) {
+            wg_barrier();                                   // A(tau)
+            wg_barrier();                                   // B(tau)
+#pragma unroll
+            for (int j = 0; j < M; ++j) ur[j] = KIND == KIND_ABS ? uctl[j] : ub[j] + uctl[j];
+            {   // IrsLqrQuasistatic.eval_cost (irs_lqr_quasistatic.py:153-194)
+                double e[NR], dv[M];
+#pragma unroll
+                for (int i = 0; i < NR; ++i) e[i] = xr[i] - a.xd[(size_t)tau * NR + i];
+#pragma unroll
+                for (int j = 0; j < M; ++j) dv[j] = ur[j] - (tau == 0 ? ub[j] : up[j]);
+                cost += quad(Qsym, e, NR) + quad(Rsym, dv, M);
+            }
+            irs_step_along<Model>(a.p, xr, ur, xn, &warm);
+#pragma unroll
+            for (int i = 0; i < NR; ++i) xr[i] = xn[i];
+#pragma unroll
+            for (int j = 0; j < M; ++j) up[j] = ur[j];
+            if (lane == 0) {
+#pragma unroll
+                for (int j = 0; j < M; ++j) a.u_new[(size_t)tau * M + j] = ur[j];
+#pragma unroll
+                for (int i = 0; i < NR; ++i) a.x_new[(size_t)(tau + 1) * NR + i] = xr[i];
+            }
+            publish_start();
+        }
+        {
+            double e[NR];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) e[i] = xr[i] - a.xd[(size_t)T * NR + i];
+            cost += quad(Qdsym, e, NR);
+        }
+        if (lane == 0 && a.cost) a.cost[0] = cost;
+        return;
+    }
+
+    // ---- the solver wave: setup ----------------------------------------------------------
     if (lane == 0) {
         a.info[0] = -1; a.info[1] = -1; a.info[2] = -1;
-        if (a.cost) a.cost[0] = __builtin_nan("");
     }
     for (int q = lane; q < NR * NR; q += 64) {
         int i = q / NR, j = q % NR;
@@ -440,47 +523,14 @@ __global__ __launch_bounds__(64) void ctrlbox_descent_kernel(BoxArgs a) {
         wave_sync();
     };
 
-    // ---- MPC loop --------------------------------------------------------------------
-    double xr[NR], ur[M], xn[NR], up[M];
-#pragma unroll
-    for (int i = 0; i < NR; ++i) xr[i] = a.x0[i];
-#pragma unroll
-    for (int j = 0; j < M; ++j) up[j] = 0.0;
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < NR; ++i) a.x_new[i] = xr[i];
-    }
-    auto quad = [&](const double* Wq, const double* e, int Kd) -> double {
-        double s = 0.0;
-        for (int i = 0; i < Kd; ++i)
-            for (int j = 0; j < Kd; ++j) s += e[i] * Wq[i * Kd + j] * e[j];
-        return s;
-    };
-    double cost = 0.0;
+    // ---- MPC loop (solver side) ----------------------------------------------------------
     int it_max = 0, n_fail = 0;
     const double tol = a.eps;
     bool full = true;                                  // no valid backward sweep yet
+    wg_barrier();                                      // S0: tables and records are up
 
     for (int tau = 0; tau < T; ++tau) {
-        // start state [x; x[idx]]: each tail's first du is measured from the realised actuated
-        // position (tv_lqr.py:99-100 at the tail's local t = 0)
-        double ub[M];
-#pragma unroll
-        for (int j = 0; j < M; ++j) {
-            double v = xr[0];
-#pragma unroll
-            for (int i = 1; i < NR; ++i) v = (i == Model::u_into_x(j)) ? xr[i] : v;
-            ub[j] = v;
-        }
-        if (lane < NS) {
-            double v = xr[0];
-#pragma unroll
-            for (int i = 1; i < NR; ++i) v = (i == lane) ? xr[i] : v;
-#pragma unroll
-            for (int j = 0; j < M; ++j) v = (NR + j == lane) ? ub[j] : v;
-            sstart[lane] = v;
-        }
-        wave_sync();
+        wg_barrier();                                  // A(tau): the plant has published this tail's start state
         const int t0 = tau;
         int t_dirty = full ? T - 1 : t0 - 1;           // the sweep of the previous tail covers t >= tau
         int iters = 0;
@@ -592,45 +642,15 @@ __global__ __launch_bounds__(64) void ctrlbox_descent_kernel(BoxArgs a) {
         if (tau == 0 && a.act_io != nullptr) {
             for (int q = lane; q < T * M; q += 64) a.act_io[q] = rec_(q / M)[L::oact + q % M];
         }
-        // first control of the tail solution (clipped), true dynamics step
-        {
+        // first control of the tail solution (clipped) -> the plant
+        if (lane < M) {
             const double* rec = rec_(tau);
-#pragma unroll
-            for (int j = 0; j < M; ++j) {
-                const double v = fmin(fmax(rec[L::ou + j], rec[L::olo + j]), rec[L::ohi + j]);
-                ur[j] = KIND == KIND_ABS ? v : ub[j] + v;
-            }
+            uctl[lane] = fmin(fmax(rec[L::ou + lane], rec[L::olo + lane]), rec[L::ohi + lane]);
         }
-        {   // IrsLqrQuasistatic.eval_cost (irs_lqr_quasistatic.py:153-194)
-            double e[NR], dv[M];
-#pragma unroll
-            for (int i = 0; i < NR; ++i) e[i] = xr[i] - a.xd[(size_t)tau * NR + i];
-#pragma unroll
-            for (int j = 0; j < M; ++j) dv[j] = ur[j] - (tau == 0 ? ub[j] : up[j]);
-            cost += quad(Qsym, e, NR) + quad(Rsym, dv, M);
-        }
-        true_step<Model>(a.p, xr, ur, xn);
-#pragma unroll
-        for (int i = 0; i < NR; ++i) xr[i] = xn[i];
-#pragma unroll
-        for (int j = 0; j < M; ++j) up[j] = ur[j];
-        if (lane == 0) {
-#pragma unroll
-            for (int j = 0; j < M; ++j) a.u_new[(size_t)tau * M + j] = ur[j];
-#pragma unroll
-            for (int i = 0; i < NR; ++i) a.x_new[(size_t)(tau + 1) * NR + i] = xr[i];
-        }
-        wave_sync();
-    }
-    {
-        double e[NR];
-#pragma unroll
-        for (int i = 0; i < NR; ++i) e[i] = xr[i] - a.xd[(size_t)T * NR + i];
-        cost += quad(Qdsym, e, NR);
+        wg_barrier();                                  // B(tau)
     }
     if (lane == 0) {
         a.info[0] = bad; a.info[1] = it_max; a.info[2] = n_fail;
-        if (a.cost) a.cost[0] = cost;
     }
 }
 
@@ -648,7 +668,7 @@ int launch_ctrlbox(const BoxArgs& a, hipStream_t st) {
         irs_set_error("irs_quasistatic_box_descent: hipFuncSetAttribute: %s", hipGetErrorString(e));
         return IRS_ERR_HIP;
     }
-    hipLaunchKernelGGL(kern, dim3(1), dim3(64), bytes, st, a);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(128), bytes, st, a);
     return IRS_OK;
 }
 

@@ -107,7 +107,7 @@ struct MfLayout {
 // 256 VGPRs + 222 AGPRs, no callee-saved registers) left the caller ~40 registers and a scratch frame to
 // park ~150 values in.
 template <class Model, int KIND, bool LDSREC>
-__global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gws) {
+__global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gws, long long* stamps) {
     constexpr int NR = Model::NX, M = Model::NU;
     using L = MfLayout<NR, M>;
     constexpr int NS = L::NS, NH = L::NH, NHP = L::NHP, KA = L::KA, RN = L::KA;   // RN: register of rows NHP..NHP+3
@@ -117,6 +117,18 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
     const int T = a.T, lane = threadIdx.x & 63, col = lane & 15, rg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // 0 solver, 1 plant
     const double tol_ = a.eps;
+    // diagnostic build only (-DIRS_CBM_STAMPS, tools/stamp_descent.sh): cycle totals per phase of the solver
+    // wave -> stamps[]; in the product build no stamp executes (stamps == nullptr, code compiled out)
+#ifdef IRS_CBM_STAMPS
+    long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define CBM_MARK(k) do { const long long st_now = __builtin_amdgcn_s_memtime(); st_acc[k] += st_now - st_mark; st_mark = st_now; } while (0)
+#define CBM_T0() const long long st_t0 = __builtin_amdgcn_s_memtime()
+#define CBM_ADD(k, n) do { st_acc[k] += __builtin_amdgcn_s_memtime() - st_t0; st_acc[(k) + 1] += (n); } while (0)
+#else
+#define CBM_T0() do {} while (0)
+#define CBM_MARK(k) do {} while (0)
+#define CBM_ADD(k, n) do {} while (0)
+#endif
 
     double* rec = LDSREC ? lds : gws;                       // per-step records
     double* sm = LDSREC ? lds + L::rec_doubles(T) : lds;    // small tables, always LDS
@@ -194,6 +206,7 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
             }
         };
         double cost = 0.0;
+        unsigned warm = ~0u;                                // active set of the previous contact step
         wg_barrier();                                       // S0
         publish_start();
         for (int tau = 0; tau < T; ++tau) {
@@ -209,7 +222,7 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
                 for (int j = 0; j < M; ++j) dv[j] = ur[j] - (tau == 0 ? ub[j] : up[j]);
                 cost += quad(Qsym, e, NR) + quad(Rsym, dv, M);
             }
-            Model::template step<double>(a.p, xr, ur, xn);
+            irs_step_along<Model>(a.p, xr, ur, xn, &warm);
 #pragma unroll
             for (int i = 0; i < NR; ++i) xr[i] = xn[i];
 #pragma unroll
@@ -361,6 +374,7 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
     // ---- backward sweep t = t_hi .. t_lo (descending): policies for the pinned sets, cost-to-go, tiles ----
     auto backward_sweep = [&](int t_hi, int t_lo) {
         if (t_hi < t_lo) return;
+        CBM_T0();
         v4d P = {0.0, 0.0, 0.0, 0.0};
         if (col < NHP) {
 #pragma unroll
@@ -381,6 +395,16 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
         };
         load_step(t_hi);
         for (int t = t_hi; t >= t_lo; --t) {
+#ifdef IRS_CBM_STAMPS
+            {   // how long the step waits for its prefetched (A, B, c)
+                const long long w0 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                st_acc[7] += __builtin_amdgcn_s_memtime() - w0;
+            }
+#endif
+#ifdef IRS_CBM_STAMPS
+            long long st_mark = __builtin_amdgcn_s_memtime();
+#endif
             v4d F;
             double Ba;
             finish_F(Fraw, F, Ba);
@@ -406,7 +430,11 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
             // Theta_nu,: (rows NHP + i sit in register RN of lanes 16 i + col).
             // The active set enters as 0/1 factors mf_i (free) -- products instead of per-element selects: a
             // lone wave pays ~5 cycles for EVERY instruction, and the step is instruction-bound.
+            asm volatile("" :: "v"(Th[0]), "v"(Th[RN]));
+            CBM_MARK(8);                                      // head + prefetch issue + 6 MFMAs
             double H[M][M], gc[M], mf[M], bz[M];
+            // (staging these through an LDS tile instead -- 1 write, 16 broadcast + 4 strided reads -- was
+            // measured equal: the phase is bound by the count of f64 instructions, ~8 cycles each for a lone wave)
 #pragma unroll
             for (int i = 0; i < M; ++i) {
 #pragma unroll
@@ -418,44 +446,78 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
                 mf[i] = ac[i] == 0.0 ? 1.0 : 0.0;
                 bz[i] = ac[i] == 0.0 ? 0.0 : bb[i];          // pinned value, 0 for a free component
             }
-            // masked LDL': free rows/columns of H, identity on the pinned ones
-            double Lm[M][M], Dg[M], Dinv[M], y[M];
+            asm volatile("" :: "v"(H[0][0]), "v"(gc[0]), "v"(gc[M - 1]));
+            CBM_MARK(9);                                      // gather of H and the lane's column
+            // Masked inverse: free rows/columns of H, identity on the pinned ones -- in CLOSED FORM (2 x 2 blocks:
+            // A^-1, the Schur complement S = C - B'A^-1 B, S^-1), not by an LDL' with substitutions.  A
+            // dependent f64 instruction of a lone wave costs ~32 cycles, an independent one ~8
+            // (tools/microbench/mfma_f64_latency.hip): the LDL' + two substitutions were a ~55-deep chain,
+            // ~1900 of the step's 2440 cycles; the block form is ~22 deep with plenty to issue beside it.
+            double Hm[M][M], Hi[M][M], y[M];
 #pragma unroll
-            for (int j = 0; j < M; ++j) {
-                double dj = H[j][j];
+            for (int i = 0; i < M; ++i)
 #pragma unroll
-                for (int l = 0; l < j; ++l) dj -= Lm[j][l] * Lm[j][l] * Dg[l];
-                dj = ac[j] == 0.0 ? dj : 1.0;
-                if (!(dj > 0.0) && bad == 0) bad = t + 1;
-                Dg[j] = dj;
-                Dinv[j] = fast_rcp_m(dj);
-                const double sj = Dinv[j] * mf[j];
-#pragma unroll
-                for (int i = j + 1; i < M; ++i) {
-                    double s = H[i][j];
-#pragma unroll
-                    for (int l = 0; l < j; ++l) s -= Lm[i][l] * Lm[j][l] * Dg[l];
-                    Lm[i][j] = s * sj * mf[i];               // zero when i or j is pinned
-                }
+                for (int j = 0; j < M; ++j) Hm[i][j] = i == j ? (ac[i] == 0.0 ? H[i][i] : 1.0) : H[i][j] * (mf[i] * mf[j]);
+            bool spd = true;
+            auto inv2 = [&](double p, double q, double r, double& ip, double& iq, double& ir) {
+                // [p q; q r]^-1 = [r -q; -q p] / (p r - q^2)
+                const double det = fma(p, r, -q * q);
+                spd = spd && p > 0.0 && det > 0.0;
+                const double id = fast_rcp_m(det);
+                ip = r * id; iq = -q * id; ir = p * id;
+            };
+            if constexpr (M == 1) {
+                spd = Hm[0][0] > 0.0;
+                Hi[0][0] = fast_rcp_m(Hm[0][0]);
+            } else if constexpr (M == 2) {
+                inv2(Hm[0][0], Hm[0][1], Hm[1][1], Hi[0][0], Hi[0][1], Hi[1][1]);
+                Hi[1][0] = Hi[0][1];
+            } else {
+                static_assert(M == 1 || M == 2 || M == 4, "closed-form inverse for 1, 2 or 4 controls");
+                double a0, a1, a2;                                   // A^-1 (symmetric: a0 a1; a1 a2)
+                inv2(Hm[0][0], Hm[0][1], Hm[1][1], a0, a1, a2);
+                // W = A^-1 B (2 x 2), S = C - B' W
+                const double w00 = fma(a0, Hm[0][2], a1 * Hm[1][2]), w01 = fma(a0, Hm[0][3], a1 * Hm[1][3]);
+                const double w10 = fma(a1, Hm[0][2], a2 * Hm[1][2]), w11 = fma(a1, Hm[0][3], a2 * Hm[1][3]);
+                const double s00 = Hm[2][2] - fma(Hm[0][2], w00, Hm[1][2] * w10);
+                const double s01 = Hm[2][3] - fma(Hm[0][2], w01, Hm[1][2] * w11);
+                const double s11 = Hm[3][3] - fma(Hm[0][3], w01, Hm[1][3] * w11);
+                double c0, c1, c2;                                   // S^-1
+                inv2(s00, s01, s11, c0, c1, c2);
+                // X = -W S^-1 (upper right), UL = A^-1 - X W'
+                const double x00 = -fma(w00, c0, w01 * c1), x01 = -fma(w00, c1, w01 * c2);
+                const double x10 = -fma(w10, c0, w11 * c1), x11 = -fma(w10, c1, w11 * c2);
+                Hi[0][0] = a0 - fma(x00, w00, x01 * w01);
+                Hi[0][1] = a1 - fma(x00, w10, x01 * w11);
+                Hi[1][1] = a2 - fma(x10, w10, x11 * w11);
+                Hi[1][0] = Hi[0][1];
+                Hi[0][2] = x00; Hi[0][3] = x01; Hi[1][2] = x10; Hi[1][3] = x11;
+                Hi[2][0] = x00; Hi[3][0] = x01; Hi[2][1] = x10; Hi[3][1] = x11;
+                Hi[2][2] = c0; Hi[2][3] = c1; Hi[3][2] = c1; Hi[3][3] = c2;
             }
+            if (!spd && bad == 0) bad = t + 1;
             const double hsel = col == NS ? 1.0 : 0.0;
+            double rhs[M];
 #pragma unroll
             for (int i = 0; i < M; ++i) {
                 // right-hand side of the free rows: Theta_f,col + (homogeneous column) sum_p H_fp b_p
-                double hb = 0.0;
+                double hb0 = 0.0, hb1 = 0.0;
 #pragma unroll
-                for (int l = 0; l < M; ++l) hb = fma(H[i][l], bz[l], hb);
-                double s = (gc[i] + hsel * hb) * mf[i];
-#pragma unroll
-                for (int l = 0; l < i; ++l) s -= Lm[i][l] * y[l];
-                y[i] = s;
+                for (int l = 0; l < M; ++l) {
+                    if (l & 1) hb1 = fma(H[i][l], bz[l], hb1);
+                    else hb0 = fma(H[i][l], bz[l], hb0);
+                }
+                rhs[i] = fma(hsel, hb0 + hb1, gc[i]) * mf[i];
             }
 #pragma unroll
-            for (int i = M - 1; i >= 0; --i) {
-                double s = y[i] * Dinv[i];
+            for (int i = 0; i < M; ++i) {
+                double y0 = 0.0, y1 = 0.0;
 #pragma unroll
-                for (int l = i + 1; l < M; ++l) s -= Lm[l][i] * y[l];
-                y[i] = s;
+                for (int l = 0; l < M; ++l) {
+                    if (l & 1) y1 = fma(Hi[i][l], rhs[l], y1);
+                    else y0 = fma(Hi[i][l], rhs[l], y0);
+                }
+                y[i] = y0 + y1;
             }
             // K~[rg][col] in B-operand layout (= K~' in A-operand layout): free rows -y, pinned rows b e_h'
             // (y = 0 on a pinned row, bz = 0 on a free one)
@@ -467,6 +529,8 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
             }
             if (rg >= M || col >= NH) Kb = 0.0;
             const bool my_free = mfree != 0.0;
+            asm volatile("" :: "v"(Kb));
+            CBM_MARK(10);                                     // inverse, right-hand sides, gains
             // D = Theta + Theta[:, nu] K~ ;  P~ = D + K~' Y, Y = rows of nu of D
             v4d D = __builtin_amdgcn_mfma_f64_16x16x4f64(Th[RN], Kb, Th, 0, 0, 0);
             v4d Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(Kb, D[RN], D, 0, 0, 0);
@@ -489,12 +553,16 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
                 for (int r = 0; r < KA; ++r) G[col * L::GR + (rg + 4 * r)] = Acl[r];        // (4 (col>>2) + (col&3)) = col
                 if (rg < M) G[col * L::GR + (NHP + rg)] = my_free ? Kb : D[RN];
             }
+            asm volatile("" :: "v"(P[0]));
+            CBM_MARK(11);                                     // 3 MFMAs, masks, record stores
         }
         rsync();
+        CBM_ADD(0, t_hi - t_lo + 1);
     };
 
     // ---- policy rollout on the linear model from sstart: controls -> `dst` (uu_ or us_), multipliers -> mu_ ----
     auto policy_rollout = [&](int t0, double* dst) {
+        CBM_T0();
         v4d S = {0.0, 0.0, 0.0, 0.0};
         if (col == 0) {
 #pragma unroll
@@ -503,38 +571,47 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
                 S[s] = k < NH ? sstart[k] : 0.0;
             }
         }
-        double g[KA], gn[KA];
-        double acn = 0.0, lon = 0.0, hin = 0.0;
         const int jj = rg < M ? rg : 0;
         const int gofs = col < L::GR ? col : 0;
-        auto fetch = [&](int t, double* gg, double& acx, double& lox, double& hix) {
+        const bool out_lane = col == 0 && rg < M;
+        struct Fw { double g[KA]; double ac, lo, hi; };
+        auto fetch = [&](int t, Fw& f) {
             const double* G = Gt + (size_t)t * L::GT;
 #pragma unroll
-            for (int s = 0; s < KA; ++s) gg[s] = G[(4 * s + rg) * L::GR + gofs];
-            acx = act_[(size_t)t * M + jj];
-            lox = lo_[(size_t)t * M + jj];
-            hix = hi_[(size_t)t * M + jj];
+            for (int s = 0; s < KA; ++s) f.g[s] = G[(4 * s + rg) * L::GR + gofs];
+            f.ac = act_[(size_t)t * M + jj];
+            f.lo = lo_[(size_t)t * M + jj];
+            f.hi = hi_[(size_t)t * M + jj];
         };
-        fetch(t0, gn, acn, lon, hin);
-        for (int t = t0; t < T; ++t) {
-#pragma unroll
-            for (int s = 0; s < KA; ++s) g[s] = gn[s];
-#pragma unroll
-            for (int s = 0; s < KA; ++s) g[s] = col < L::GR ? g[s] : 0.0;
-            const double acx = acn, bdx = acn < 0.0 ? lon : hin;
-            if (t + 1 < T) fetch(t + 1, gn, acn, lon, hin);
+        // one step: [s~+; out] = G_t s~ (KA chained MFMAs), outputs to the iterate / multiplier vectors
+        auto step = [&](int t, const Fw& f, const v4d& Sin, v4d& Sout) {
             v4d Dn = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int s = 0; s < KA; ++s) Dn = __builtin_amdgcn_mfma_f64_16x16x4f64(g[s], S[s], Dn, 0, 0, 0);
-            if (col == 0 && rg < M) {
+            for (int s = 0; s < KA; ++s)
+                Dn = __builtin_amdgcn_mfma_f64_16x16x4f64(col < L::GR ? f.g[s] : 0.0, Sin[s], Dn, 0, 0, 0);
+            if (out_lane) {
                 const double o = Dn[RN];                       // K~_j s~ (free) or the multiplier Y_j s~ (pinned)
-                dst[(size_t)t * M + rg] = acx == 0.0 ? o : bdx;
-                mu_[(size_t)t * M + rg] = acx == 0.0 ? 0.0 : o;
+                const double bd = f.ac < 0.0 ? f.lo : f.hi;
+                dst[(size_t)t * M + rg] = f.ac == 0.0 ? o : bd;
+                mu_[(size_t)t * M + rg] = f.ac == 0.0 ? 0.0 : o;
             }
-#pragma unroll
-            for (int s = 0; s < KA; ++s) S[s] = Dn[s];
+            Sout = Dn;
+        };
+        // two steps per trip: the prefetched operands and the state tile alternate between two register sets,
+        // so nothing is copied at the back edge (a lone wave pays ~5 cycles for every v_mov)
+        Fw fa, fb;
+        v4d S1;
+        fetch(t0, fa);
+        int t = t0;
+        for (; t + 1 < T; t += 2) {
+            fetch(t + 1, fb);
+            step(t, fa, S, S1);
+            if (t + 2 < T) fetch(t + 2, fa);
+            step(t + 1, fb, S1, S);
         }
+        if (t < T) step(t, fa, S, S1);
         rsync();
+        CBM_ADD(2, T - t0);
     };
 
     // ---- cold start of the first tail: the SATURATED unconstrained policy.  With every component free the
@@ -592,13 +669,20 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
     };
 
     // ---- MPC loop (solver side) ----------------------------------------------------------
+#ifdef IRS_CBM_STAMPS
+    const long long st_begin = __builtin_amdgcn_s_memtime();
+#endif
     int it_max = 0, n_fail = 0;
     const double tol = a.eps;
     bool full = true;                                  // no valid backward sweep yet
     wg_barrier();                                      // S0: tables and records are up
 
     for (int tau = 0; tau < T; ++tau) {
-        wg_barrier();                                  // A(tau): the plant has published this tail's start state
+        {
+            CBM_T0();
+            wg_barrier();                              // A(tau): the plant has published this tail's start state
+            CBM_ADD(4, 1);
+        }
         const int t0 = tau;
         if (tau == 0) {
             // no warm start handed in (act_io absent or all zero): start from the saturated policy
@@ -719,9 +803,29 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
     if (lane == 0) {
         a.info[0] = bad; a.info[1] = it_max; a.info[2] = n_fail;
     }
+#ifdef IRS_CBM_STAMPS
+    if (lane == 0 && stamps != nullptr) {
+        st_acc[6] = __builtin_amdgcn_s_memtime() - st_begin;
+        for (int k = 0; k < 16; ++k) stamps[k] = st_acc[k];
+    }
+#endif
 }
 
 constexpr size_t kLdsMax = 160 * 1024 - 512;
+
+// diagnostic build: a device buffer for the stamps, printed (and reset) by irs_cbm_print_stamps()
+#ifdef IRS_CBM_STAMPS
+static long long* g_stamps = nullptr;
+static long long* cbm_stamps() {
+    if (g_stamps == nullptr) {
+        (void)hipMalloc(reinterpret_cast<void**>(&g_stamps), 16 * sizeof(long long));
+        (void)hipMemset(g_stamps, 0, 16 * sizeof(long long));
+    }
+    return g_stamps;
+}
+#else
+static long long* cbm_stamps() { return nullptr; }
+#endif
 
 template <class Model, int KIND>
 int launch_ctrlbox_mfma(const BoxArgs& a, double* ws, size_t ws_bytes, hipStream_t st) {
@@ -742,10 +846,10 @@ int launch_ctrlbox_mfma(const BoxArgs& a, double* ws, size_t ws_bytes, hipStream
             irs_set_error("irs_quasistatic_box_descent: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return IRS_ERR_HIP;
         }
-        hipLaunchKernelGGL(kern, dim3(1), dim3(128), bytes, st, a, (double*)nullptr);
+        hipLaunchKernelGGL(kern, dim3(1), dim3(128), bytes, st, a, (double*)nullptr, cbm_stamps());
     } else {
         auto kern = ctrlbox_mfma_kernel<Model, KIND, false>;
-        hipLaunchKernelGGL(kern, dim3(1), dim3(128), bytes, st, a, ws);
+        hipLaunchKernelGGL(kern, dim3(1), dim3(128), bytes, st, a, ws, cbm_stamps());
     }
     return IRS_OK;
 }
@@ -792,3 +896,16 @@ int irs_ctrlbox_mfma_launch(int model, const BoxArgs& a, int kind, double* ws, s
     });
     return rc;
 }
+
+#ifdef IRS_CBM_STAMPS
+// diagnostic build only: cycle totals of the LAST launch's solver wave
+extern "C" void irs_cbm_print_stamps(void) {
+    long long h[16];
+    (void)hipDeviceSynchronize();
+    if (g_stamps == nullptr || hipMemcpy(h, g_stamps, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
+    fprintf(stderr, "[cbm stamps] backward %lld cyc / %lld steps; forward %lld cyc / %lld steps; wait for plant %lld cyc / "
+                    "%lld tails; MPC loop %lld cyc; of backward: waiting for the prefetched step data %lld cyc\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+    fprintf(stderr, "[cbm stamps] backward step phases: head+6 MFMA %lld, gather %lld, inverse+gains %lld, 3 MFMA+stores %lld cyc\n",
+            h[8], h[9], h[10], h[11]);
+}
+#endif

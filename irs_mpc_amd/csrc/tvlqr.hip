@@ -872,6 +872,7 @@ __device__ __forceinline__ void rollout_device(const ModelParams& p, int T, cons
         };
         fetch(0, true);
         double cost = 0.0;
+        unsigned warm_set = ~0u;      // active set of the previous contact step (exact step QPs only)
         for (int t = 0; t < T; ++t) {
             double e[n];
 #pragma unroll
@@ -900,7 +901,7 @@ __device__ __forceinline__ void rollout_device(const ModelParams& p, int T, cons
                 for (int j = 0; j < m; ++j) r += Rr[i][j] * u[j];
                 cost += u[i] * r;
             }
-            Model::template step<double>(p, x, u, xn);
+            irs_step_along<Model>(p, x, u, xn, &warm_set);
 #pragma unroll
             for (int i = 0; i < n; ++i) x[i] = xn[i];
             if (lane == 0) {
@@ -952,6 +953,7 @@ __device__ __forceinline__ void rollout_device(const ModelParams& p, int T, cons
     // i < n owns the i-th row of e'Qe; each lane accumulates its share of the cost over
     // all t and the wave is reduced ONCE at the end.  Only the dynamics step is redundant.
     double cost = 0.0;
+    unsigned warm_set = ~0u;
     auto pick = [&](const double* v, int len) {       // v[lane] without dynamic register indexing
         double r = v[0];
 #pragma unroll
@@ -994,7 +996,7 @@ __device__ __forceinline__ void rollout_device(const ModelParams& p, int T, cons
             for (int j = 0; j < m; ++j) r += S.R[lane * m + j] * u[j];
             cost += pick(u, m) * r;
         }
-        Model::template step<double>(p, x, u, xn);
+        irs_step_along<Model>(p, x, u, xn, &warm_set);
 #pragma unroll
         for (int i = 0; i < n; ++i) x[i] = xn[i];
         if (lane == 0) {

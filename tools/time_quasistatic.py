@@ -51,5 +51,11 @@ for cname, b in cases.items():
         dt = (time.perf_counter() - t0) / reps
         u = out["u_new"].cpu().numpy()
         d = np.abs(u - ref.setdefault(cname, u)).max()
+        if "--stamps" in sys.argv and solver == 3:
+            import ctypes
+            lib = _lib.load()
+            if hasattr(lib, "irs_cbm_print_stamps"):
+                lib.irs_cbm_print_stamps.restype = None
+                lib.irs_cbm_print_stamps()
         print("%s T=%d %-4s %-10s %9.3f ms/descent  cost %.6f  info %s  |u - first solver's| %.1e"
               % (name, T, cname, label, dt * 1e3, float(out["cost"].item()), out["info"].cpu().numpy().tolist(), d), flush=True)
