@@ -332,6 +332,29 @@ int irs_quasistatic_box_descent_ws(int model, const double *params, int n_params
                                    double *x_new, double *u_new, double *cost, int *info,
                                    double *act_io, void *stream);
 size_t irs_quasistatic_box_lds_bytes(int model, int T, int solver);
+/* solve_tvlqr stand-alone (irs_lqr/tv_lqr.py:30-145): ONE QP, possibly bounded, its plan returned -- what a
+ * caller outside the MPC loops gets from the reference function.  `model` only selects the compiled (n, m)
+ * (and, position_controlled = 1: indices_u_into_x, tv_lqr.py:96-108, cost on du_t = u_t - u_{t-1} with
+ * du_0 = u_0 - x0[idx], full R); its dynamics are not used.  Bounds: per-time rows, DEV f64, NULL = absent,
+ * +-inf allowed: x_lo,x_hi (T+1,n) [x_bound_abs, :112-115; row 0 is not enforced: x_0 is data], u_lo,u_hi (T,m)
+ * [u_bound_abs, :116-118], du_lo,du_hi (T,m) [u_bound_rel, :122-125; position-controlled form only].
+ * x_bound_rel (:119-121) is not supported.  alpha_R: 1/2 for the plain branch (Drake's AddQuadraticCost(R, 0, u),
+ * :110), 1 for the position-controlled one (:107).  ADMM around one Riccati factorisation (csrc/boxqp.hip);
+ * x_star (T+1,n), u_star (T,m) DEV out; info (3) as for irs_tvlqr_box_descent.                              */
+int irs_tvlqr_box_solve(int model, const double *params, int n_params, int T,
+                        const double *At, const double *Bt, const double *ct,
+                        const double *Q, const double *Qd, const double *R, double alpha_R,
+                        const double *xd_trj, const double *x0, int position_controlled,
+                        const double *x_lo, const double *x_hi, const double *u_lo, const double *u_hi,
+                        const double *du_lo, const double *du_hi,
+                        double rho, double relax, int max_iter, double eps,
+                        double *x_star, double *u_star, int *info, void *stream);
+/* IrsLqrZeroOrder.compute_least_squares (irs_lqr/irs_lqr_zero_order.py:27-36) stand-alone: dxdu (N, n+m),
+ * deltaf (N, n) DEV f64 -> A (n,n), B (n,m) with [A | B] = lstsq(dxdu, deltaf)[0]'.  Normal equations in f64,
+ * Jacobi-scaled Cholesky (the solve the sample pass ends with).  info (1): 0, the failed pivot (1-based: a
+ * rank-deficient design), or n+m+1 for non-finite data.  n <= 32, m <= 16.                                   */
+int irs_least_squares(int n, int m, int N, const double *dxdu, const double *deltaf, double *A, double *B,
+                      int *info, void *stream);
 /* The same with a device workspace for horizons whose per-step records do not fit the 160 KB of LDS
  * (solver 3 / 0): `workspace` DEV, at least irs_quasistatic_descent_workspace_bytes(model, T, solver)
  * bytes (0 = none needed: pass NULL); uninitialised scratch, no state is kept in it between calls.  The
@@ -411,6 +434,30 @@ typedef struct irs_descent_call {
 
 /* irs_tvlqr_descent, by struct.                                                    */
 int irs_descent_run(const irs_descent_call *call, void *stream);
+
+/* ---- the multi-GPU smoothing step inside the library (csrc/collective.hip) ------------------------------
+ * One process per GPU; samples sharded over the ranks; per step: sample pass -> ONE all-reduce of the
+ * (T,P) f64 statistics (RCCL over xGMI) -> solve (every rank, redundantly).  Replaces the reference's ZeroMQ
+ * worker pool (zmq_parallel_cmp/array_io.py:6-26, irs_lqr/irs_lqr_quasistatic.py:245-263).  RCCL is bound at
+ * run time (the copy torch.distributed's "nccl" backend loaded, if any).
+ *   irs_comm_unique_id   rank 0 fills 128 bytes (ncclGetUniqueId); the host distributes them to all ranks
+ *   irs_comm_create      collective: every rank, with its device current (ncclCommInitRank)
+ *   irs_allreduce_sums   in-place f64 SUM all-reduce of `count` doubles on `stream`
+ *   irs_smooth_step_collective   the three enqueues (accumulate, all-reduce, solve) on `stream`; `call` must
+ *                        carry sums AND At/Bt/ct/info, n_total = samples per timestep over all ranks, and, for
+ *                        device-drawn samples, sample_offset = this rank's first global sample; comm may be NULL
+ *                        (one rank: no collective)
+ *   irs_step_graph_*     the same three enqueues captured ONCE into a HIP graph (on `stream`, which must not be
+ *                        the default stream) and replayed with one call per step: the step is ~70-100 us of
+ *                        device work in three launches, which a host issuing them one by one cannot keep fed */
+int irs_comm_unique_id(void *id128);
+int irs_comm_create(const void *id128, int nranks, int rank, void **comm);
+int irs_comm_destroy(void *comm);
+int irs_allreduce_sums(void *comm, double *sums, size_t count, void *stream);
+int irs_smooth_step_collective(const irs_smooth_call *call, void *comm, void *stream);
+int irs_step_graph_create(const irs_smooth_call *call, void *comm, void *stream, void **graph_exec);
+int irs_step_graph_launch(void *graph_exec, void *stream);
+int irs_step_graph_destroy(void *graph_exec);
 
 #ifdef __cplusplus
 }

@@ -113,8 +113,20 @@ SIGNATURES["irs_quasistatic_box_descent_wsx"] = (c_int, [c_int, POINTER(c_double
                                                          c_double, c_int, c_double, _dp, _dp, _dp, _dp, _dp, _dp,
                                                          c_size_t, c_void_p])
 SIGNATURES["irs_quasistatic_descent_workspace_bytes"] = (c_size_t, [c_int, c_int, c_int])
+SIGNATURES["irs_tvlqr_box_solve"] = (c_int, [c_int, POINTER(c_double), c_int, c_int, _dp, _dp, _dp, _dp, _dp, _dp, c_double,
+                                             _dp, _dp, c_int, _dp, _dp, _dp, _dp, _dp, _dp, c_double, c_double, c_int,
+                                             c_double, _dp, _dp, _dp, c_void_p])
+SIGNATURES["irs_least_squares"] = (c_int, [c_int, c_int, c_int, _dp, _dp, _dp, _dp, _dp, c_void_p])
 SIGNATURES["irs_smooth_run"] = (c_int, [POINTER(SmoothCall), c_void_p])
 SIGNATURES["irs_descent_run"] = (c_int, [POINTER(DescentCall), c_void_p])
+SIGNATURES["irs_comm_unique_id"] = (c_int, [c_void_p])
+SIGNATURES["irs_comm_create"] = (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)])
+SIGNATURES["irs_comm_destroy"] = (c_int, [c_void_p])
+SIGNATURES["irs_allreduce_sums"] = (c_int, [c_void_p, _dp, c_size_t, c_void_p])
+SIGNATURES["irs_smooth_step_collective"] = (c_int, [POINTER(SmoothCall), c_void_p, c_void_p])
+SIGNATURES["irs_step_graph_create"] = (c_int, [POINTER(SmoothCall), c_void_p, c_void_p, POINTER(c_void_p)])
+SIGNATURES["irs_step_graph_launch"] = (c_int, [c_void_p, c_void_p])
+SIGNATURES["irs_step_graph_destroy"] = (c_int, [c_void_p])
 
 _lib = None
 

@@ -386,6 +386,17 @@ __global__ __launch_bounds__(64) void box_descent_kernel(BoxArgs a) {
         }
         it_max = max(it_max, it);
         n_fail += conv ? 0 : 1;
+        if (a.single_tail) {
+            // solve_tvlqr's return value: the plan of this one QP (xt_star (T+1,n), ut_star (T,m)) -- the
+            // linear-model rollout of the converged iterate; for DU the controls are the u_prev blocks
+            for (int q = lane; q < (T + 1) * NR; q += 64) a.x_new[q] = zx[(size_t)(q / NR) * N + q % NR];
+            for (int q = lane; q < T * M; q += 64)
+                a.u_new[q] = DU ? zx[(size_t)(q / M + 1) * N + NR + q % M] : zu[q];
+            if (lane == 0) {
+                a.info[0] = bad; a.info[1] = it_max; a.info[2] = n_fail;
+            }
+            return;
+        }
         // first control of the tail solution (clipped), true dynamics step
 #pragma unroll
         for (int j = 0; j < M; ++j) {
@@ -481,6 +492,7 @@ int irs_tvlqr_box_descent(int model, const double* params, int n_params, int T, 
     IRS_CHECK_ARG(rho > 0.0 && relax > 0.0 && relax < 2.0 && max_iter > 0 && eps > 0.0, "bad ADMM parameter");
     BoxArgs a;
     a.act_io = nullptr;
+    a.single_tail = 0;
     int rc = irs_load_params(model, params, n_params, &a.p);
     if (rc != IRS_OK) return rc;
     a.At = At; a.Bt = Bt; a.ct = ct; a.Q = Q; a.Qd = Qd; a.R = R; a.xd = xd_trj; a.x0 = x0;
@@ -542,6 +554,7 @@ int irs_quasistatic_box_descent_wsx(int model, const double* params, int n_param
     IRS_CHECK_ARG(rho > 0.0 && relax > 0.0 && relax < 2.0 && max_iter > 0 && eps > 0.0, "bad ADMM parameter");
     BoxArgs a;
     a.act_io = act_io;
+    a.single_tail = 0;
     int rc = irs_load_params(model, params, n_params, &a.p);
     if (rc != IRS_OK) return rc;
     int n, m, np;
@@ -584,6 +597,45 @@ int irs_quasistatic_box_descent_wsx(int model, const double* params, int n_param
         if constexpr (has_u_into_x<Model>::value) rc = launch_box<Model, true>(a, st);
         else irs_set_error("irs_quasistatic_box_descent: model %d is not position controlled", model);
     });
+    if (rc != IRS_OK) return rc;
+    IRS_CHECK_LAUNCH();
+    return IRS_OK;
+}
+
+// solve_tvlqr (irs_lqr/tv_lqr.py:30-145) stand-alone: ONE bounded QP, its plan returned.
+int irs_tvlqr_box_solve(int model, const double* params, int n_params, int T, const double* At, const double* Bt,
+                        const double* ct, const double* Q, const double* Qd, const double* R, double alpha_R,
+                        const double* xd_trj, const double* x0, int position_controlled,
+                        const double* x_lo, const double* x_hi, const double* u_lo, const double* u_hi,
+                        const double* du_lo, const double* du_hi, double rho, double relax, int max_iter,
+                        double eps, double* x_star, double* u_star, int* info, void* stream) {
+    IRS_CHECK_ARG(T > 0 && At && Bt && ct && Q && Qd && R && xd_trj && x0 && x_star && u_star && info, "bad argument");
+    IRS_CHECK_ARG((x_lo == nullptr) == (x_hi == nullptr) && (u_lo == nullptr) == (u_hi == nullptr) &&
+                  (du_lo == nullptr) == (du_hi == nullptr), "give both sides of a bound or neither");
+    IRS_CHECK_ARG(position_controlled || du_lo == nullptr, "du bounds need the position-controlled form");
+    IRS_CHECK_ARG(rho > 0.0 && relax > 0.0 && relax < 2.0 && max_iter > 0 && eps > 0.0, "bad ADMM parameter");
+    BoxArgs a;
+    a.act_io = nullptr;
+    a.single_tail = 1;
+    int rc = irs_load_params(model, params, n_params, &a.p);
+    if (rc != IRS_OK) return rc;
+    int n, m, np;
+    irs_model_info(model, &n, &m, &np);
+    a.At = At; a.Bt = Bt; a.ct = ct; a.Q = Q; a.Qd = Qd; a.R = R; a.xd = xd_trj; a.x0 = x0;
+    a.xlo = x_lo; a.xhi = x_hi; a.ulo = u_lo; a.uhi = u_hi; a.dlo = du_lo; a.dhi = du_hi;
+    a.sx = n; a.su = m; a.sd = m;
+    a.x_new = x_star; a.u_new = u_star; a.cost = nullptr; a.info = info;
+    a.alpha = alpha_R; a.rho = rho; a.relax = relax; a.eps = eps; a.T = T; a.max_iter = max_iter;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = IRS_ERR_UNSUPPORTED;
+    if (position_controlled) {
+        IRS_DISPATCH_MODEL(model, {
+            if constexpr (has_u_into_x<Model>::value) rc = launch_box<Model, true>(a, st);
+            else irs_set_error("irs_tvlqr_box_solve: model %d is not position controlled", model);
+        });
+    } else {
+        IRS_DISPATCH_MODEL(model, { rc = launch_box<Model, false>(a, st); });
+    }
     if (rc != IRS_OK) return rc;
     IRS_CHECK_LAUNCH();
     return IRS_OK;

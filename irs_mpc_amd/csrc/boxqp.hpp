@@ -21,6 +21,9 @@ struct BoxArgs {
     // the FIRST tail starts from (zeros = cold start); out: the set that tail converged to -- what the
     // next iLQR iteration's descent should start from
     double* act_io;
+    // ADMM kernel only: 1 = solve the FIRST tail problem alone and return its plan (x*, u*) in x_new / u_new --
+    // the stand-alone solve_tvlqr (irs_lqr/tv_lqr.py:30-145); no true-dynamics step is taken
+    int single_tail;
 };
 
 // position-controlled models expose indices_u_into_x (quasistatic_dynamics.py:57-65)

@@ -1076,6 +1076,89 @@ __global__ __launch_bounds__(64) void evaluate_cost_kernel(int n, int m, int T, 
 
 }  // namespace
 
+// IrsLqrZeroOrder.compute_least_squares (irs_lqr/irs_lqr_zero_order.py:27-36) stand-alone:
+//   ABhat = lstsq([dx du] (N x d), deltaf (N x n))[0]'   ->   A (n x n), B (n x m)
+// One workgroup: the Gram matrix Z'Z and the cross term Z'dF are accumulated in f64 (every thread owns
+// entries and walks the N rows), then one wave solves the Jacobi-scaled normal equations by Cholesky --
+// the same solve the sample pass ends with (smooth.hip, finalize_timestep), for supplied samples and
+// without a model.  info = 0, or the 1-based pivot that failed (rank-deficient design), or d + 1 for a
+// non-finite entry.
+__global__ __launch_bounds__(256) void lstsq_kernel(int n, int m, int N, const double* Z, const double* dF,
+                                                    double* A, double* B, int* info) {
+    constexpr int D = kMaxN + kMaxM;
+    __shared__ double G[D][D + 1];
+    __shared__ double H[D][kMaxN];
+    __shared__ double sc[D];
+    __shared__ int bad;
+    const int d = n + m, tid = threadIdx.x;
+    if (tid == 0) bad = 0;
+    for (int q = tid; q < d * d; q += 256) {
+        const int i = q / d, j = q % d;
+        if (j < i) continue;
+        double s = 0.0;
+        for (int r = 0; r < N; ++r) s = fma(Z[(size_t)r * d + i], Z[(size_t)r * d + j], s);
+        G[i][j] = s;
+        G[j][i] = s;
+    }
+    for (int q = tid; q < d * n; q += 256) {
+        const int i = q / n, k = q % n;
+        double s = 0.0;
+        for (int r = 0; r < N; ++r) s = fma(Z[(size_t)r * d + i], dF[(size_t)r * n + k], s);
+        H[i][k] = s;
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    const int lane = tid;
+    auto wsync = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    };
+    if (lane < d) {
+        const double g = G[lane][lane];
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(g);
+        if ((bits & 0x7ff0000000000000ull) == 0x7ff0000000000000ull) bad = d + 1;
+        else if (!(g > 0.0)) bad = lane + 1;
+        sc[lane] = g > 0.0 ? 1.0 / sqrt(g) : 0.0;
+    }
+    wsync();
+    for (int q = lane; q < d * d; q += 64) G[q / d][q % d] *= sc[q / d] * sc[q % d];
+    for (int q = lane; q < d * n; q += 64) H[q / n][q % n] *= sc[q / n];
+    wsync();
+    for (int j = 0; j < d; ++j) {                        // right-looking Cholesky, forward substitution folded in
+        double djj = G[j][j];
+        if (!(djj > 1e-14)) {
+            if (lane == 0 && bad == 0) bad = j + 1;
+            djj = 1.0;
+        }
+        const double il = 1.0 / sqrt(djj);
+        wsync();
+        if (lane == j) G[j][j] = il;
+        for (int r = j + 1 + lane; r < d; r += 64) G[r][j] *= il;
+        for (int k = lane; k < n; k += 64) H[j][k] *= il;
+        wsync();
+        for (int q = lane; q < d * d; q += 64) {
+            const int r = q / d, c = q % d;
+            if (c > j && r >= c) G[r][c] -= G[r][j] * G[c][j];
+        }
+        for (int q = lane; q < d * n; q += 64) {
+            const int r = q / n, k = q % n;
+            if (r > j) H[r][k] -= G[r][j] * H[j][k];
+        }
+        wsync();
+    }
+    for (int i = d - 1; i >= 0; --i) {                   // L' w = y, column oriented
+        const double il = G[i][i];
+        wsync();
+        for (int k = lane; k < n; k += 64) H[i][k] *= il;
+        wsync();
+        for (int q = lane; q < i * n; q += 64) H[q / n][q % n] -= G[i][q / n] * H[i][q % n];
+    }
+    wsync();
+    for (int q = lane; q < n * n; q += 64) A[q] = H[q % n][q / n] * sc[q % n];                 // ABhat[k][i] = X[i][k]
+    for (int q = lane; q < n * m; q += 64) B[q] = H[n + q % m][q / m] * sc[n + q % m];
+    if (lane == 0) info[0] = bad;
+}
+
 extern "C" {
 
 int irs_evaluate_cost(int n, int m, int T, const double* x_trj, const double* u_trj, const double* Q,
@@ -1101,6 +1184,16 @@ int irs_tvlqr_riccati(int n, int m, int T, const double* At, const double* Bt, c
     else if (n == 6 && m == 2) hipLaunchKernelGGL((riccati_kernel_t<6, 2>), dim3(1), dim3(64), 0, st, a);
     else if (n == 7 && m == 4) hipLaunchKernelGGL((riccati_kernel_t<7, 4>), dim3(1), dim3(64), 0, st, a);
     else hipLaunchKernelGGL(riccati_kernel, dim3(1), dim3(64), 0, st, a);
+    IRS_CHECK_LAUNCH();
+    return IRS_OK;
+}
+
+int irs_least_squares(int n, int m, int N, const double* dxdu, const double* deltaf, double* A, double* B,
+                      int* info, void* stream) {
+    IRS_CHECK_ARG(n > 0 && n <= kMaxN && m > 0 && m <= kMaxM && N > 0, "need 0<n<=32, 0<m<=16, N>0");
+    IRS_CHECK_ARG(dxdu && deltaf && A && B && info, "null pointer");
+    hipLaunchKernelGGL(lstsq_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), n, m, N, dxdu, deltaf,
+                       A, B, info);
     IRS_CHECK_LAUNCH();
     return IRS_OK;
 }

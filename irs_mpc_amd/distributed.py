@@ -60,3 +60,86 @@ def capture_step(fn, warmup=3):
         fn()
     torch.cuda.synchronize()
     return graph.replay
+
+
+class DirectComm:
+    """An RCCL communicator owned by the HIP library (include/irs_hip.h, irs_comm_*): the unique id is made on
+    rank 0 and handed to the other ranks through torch.distributed (whatever its backend: the id is 128 host
+    bytes); every rank then joins with its current device.  With it the whole multi-GPU smoothing step --
+    sample pass, all-reduce of the (T,P) sums, solve -- is enqueued, or captured into one HIP graph, INSIDE the
+    library (`CollectiveStep`), without torch's collectives in the data path."""
+
+    def __init__(self, group=None):
+        import ctypes
+        from . import _lib
+        self.lib = _lib.load()
+        self.rank, self.world = rank_world()
+        ident = (ctypes.c_char * 128)()
+        if self.rank == 0:
+            _lib.check(self.lib.irs_comm_unique_id(ctypes.cast(ident, ctypes.c_void_p)), "irs_comm_unique_id")
+        if self.world > 1:
+            t = torch.frombuffer(bytearray(bytes(ident)), dtype=torch.uint8).clone()
+            if dist.get_backend(group) == "nccl":
+                t = t.cuda()
+            dist.broadcast(t, src=0, group=group)
+            ident = (ctypes.c_char * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
+        self.handle = ctypes.c_void_p()
+        _lib.check(self.lib.irs_comm_create(ctypes.cast(ident, ctypes.c_void_p), self.world, self.rank,
+                                            ctypes.byref(self.handle)), "irs_comm_create")
+
+    def all_reduce_sums(self, sums):
+        from . import _lib
+        _lib.check(self.lib.irs_allreduce_sums(self.handle, sums.data_ptr(), sums.numel(),
+                                               torch.cuda.current_stream().cuda_stream), "irs_allreduce_sums")
+        return sums
+
+    def destroy(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            self.lib.irs_comm_destroy(self.handle)
+            self.handle = None
+
+
+class CollectiveStep:
+    """One multi-GPU smoothing step of a `SmoothPlan` built with fuse=True outputs AND sums (accumulate ->
+    all-reduce -> solve), issued by the library: `run()` enqueues the three launches, `capture()` records them
+    once into a HIP graph and `run()` then replays it with a single call."""
+
+    def __init__(self, plan, comm=None):
+        import ctypes
+        from . import _lib
+        self.plan, self.comm, self.lib = plan, comm, _lib.load()
+        self._ref = ctypes.byref(plan.call)
+        self._graph = ctypes.c_void_p()
+        self._check = _lib.check
+        assert plan.out is not None, "build the SmoothPlan with fuse=True: the step needs At/Bt/ct/info"
+
+    def _comm(self):
+        return self.comm.handle if self.comm is not None else None
+
+    def capture(self):
+        import ctypes
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):              # warm-up on the capture stream (RCCL sets its channels up lazily)
+                self._check(self.lib.irs_smooth_step_collective(self._ref, self._comm(), side.cuda_stream),
+                            "irs_smooth_step_collective")
+            side.synchronize()
+            self._check(self.lib.irs_step_graph_create(self._ref, self._comm(), side.cuda_stream,
+                                                       ctypes.byref(self._graph)), "irs_step_graph_create")
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        return self
+
+    def run(self):
+        st = torch.cuda.current_stream().cuda_stream
+        if self._graph.value:
+            self._check(self.lib.irs_step_graph_launch(self._graph, st), "irs_step_graph_launch")
+        else:
+            self._check(self.lib.irs_smooth_step_collective(self._ref, self._comm(), st), "irs_smooth_step_collective")
+        return self.plan.out
+
+    def destroy(self):
+        if self._graph.value:
+            self.lib.irs_step_graph_destroy(self._graph)
+            self._graph.value = None

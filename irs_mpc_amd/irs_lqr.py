@@ -310,10 +310,22 @@ class IrsLqrZeroOrder(_IrsLqrSampled):
     MODE = SMOOTH_ZERO_ORDER_AB
 
     def compute_least_squares(self, dxdu, deltaf):
-        """irs_lqr_zero_order.py:27-36, for callers that use it stand-alone: the same
-        normal-equation solve the device performs, fed through the device finalize."""
-        raise NotImplementedError("compute_least_squares is fused into the device sample pass; "
-                                  "use get_TV_matrices")
+        """irs_lqr_zero_order.py:27-36, for callers that use it stand-alone: ABhat = lstsq(dxdu, deltaf)[0]',
+        split into (Ahat (n,n), Bhat (n,m)) -- normal equations + Jacobi-scaled Cholesky on the device
+        (irs_least_squares), the solve `get_TV_matrices` ends with."""
+        Z = dev.to_dev(np.asarray(dxdu, float))
+        dF = dev.to_dev(np.asarray(deltaf, float))
+        n, m = self.dim_x, self.dim_u
+        assert Z.shape[1] == n + m and dF.shape == (Z.shape[0], n)
+        A = torch.empty((n, n), dtype=dev.F64, device=Z.device)
+        B = torch.empty((n, m), dtype=dev.F64, device=Z.device)
+        info = torch.empty((1,), dtype=torch.int32, device=Z.device)
+        from ._lib import check, load
+        check(load().irs_least_squares(n, m, Z.shape[0], Z.data_ptr(), dF.data_ptr(), A.data_ptr(), B.data_ptr(),
+                                       info.data_ptr(), dev._stream()), "irs_least_squares")
+        if int(info.item()) != 0:
+            raise ValueError("randomized-smoothing least squares is rank deficient (or has non-finite data)")
+        return A.cpu().numpy(), B.cpu().numpy()
 
 
 class IrsLqrFirstOrder(_IrsLqrSampled):

@@ -84,6 +84,14 @@ def test_argument_validation_without_gpu(lib):
     assert lib.irs_smooth_finalize_ws(4, ph, 12, 2, 50, 100, one, one, one, one, one, one, one, one, 64, None) == -1
     assert lib.irs_cem_rollout_costs_quasistatic(4, ph, 12, 10, 0, one, one, one, one, one, one, one, None) == -1
     assert lib.irs_model_info(11, None, None, None) != 0                     # ids 0..10 are registered
+    # the in-library collective step: argument validation happens before RCCL or the GPU are touched
+    assert lib.irs_comm_destroy(None) == 0 and lib.irs_step_graph_destroy(None) == 0
+    assert lib.irs_comm_create(None, 1, 0, None) == -1
+    assert lib.irs_allreduce_sums(None, None, 0, None) == -1
+    assert lib.irs_smooth_step_collective(None, None, None) == -1
+    assert lib.irs_least_squares(0, 1, 10, one, one, one, one, one, None) == -1
+    assert lib.irs_tvlqr_box_solve(4, ph, 12, 10, *args[:6], 0.5, one, one, 0, None, None, None, None, one, one,
+                                   10.0, 1.6, 100, 1e-8, one, one, one, None) == -1   # du bounds need the position form
 
 
 def test_product_does_not_import_oracle():

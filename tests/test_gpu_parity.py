@@ -16,6 +16,7 @@ import torch
 from oracle import irs_oracle as orc
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # the stated fp32 tolerance of the sample pass against the f64 oracle on identical samples;
 # measured on the device: ~1e-6 for the analytic AND the contact models (tools/contact_tolerance_probe.py)
@@ -391,11 +392,77 @@ def test_solve_tvlqr_matches_qp(amd):
     xq, uq = orc.solve_tvlqr_qp(At, Bt, ct, p.Q, p.Qd, p.R, p.x0, p.xd_trj)
     np.testing.assert_allclose(us, uq, rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(xs, xq, rtol=1e-6, atol=1e-7)
-    with pytest.raises(NotImplementedError):
-        amd.solve_tvlqr(At, Bt, ct, p.Q, p.Qd, p.R, p.x0, p.xd_trj, None,
-                        u_bound_abs=np.stack([np.full((8, 4), -0.1), np.full((8, 4), 0.1)]))
+    # inactive bounds: the Riccati solution stands
+    wide = np.stack([np.full((8, 4), -1e3), np.full((8, 4), 1e3)])
+    xs2, us2 = amd.solve_tvlqr(At, Bt, ct, p.Q, p.Qd, p.R, p.x0, p.xd_trj, None, u_bound_abs=wide)
+    np.testing.assert_array_equal(us2, us)
     with pytest.raises(ValueError):
         amd.get_solver("nope")
+
+
+def test_solve_tvlqr_bounded_stand_alone(amd):
+    """solve_tvlqr with ACTIVE bounds as a stand-alone call (tv_lqr.py:112-137): one launch of the bounded
+    kernel for a single tail.  Certified against the QP's KKT conditions (oracle, independent of any solver)
+    and equal to the oracle's ADMM solution.  Plain form (bicycle: steer bound + input bound, alpha_R = 1/2)
+    and position-controlled form (planar hand: indices_u_into_x, cost on du, trust region + rate limit)."""
+    # ---- plain form
+    sys_o = orc.BicycleOracle(0.1)
+    p = bike_params(amd, 25)
+    x = orc.rollout(sys_o, p.x0, p.u_trj_initial)
+    At, Bt, ct = orc.exact_TV(sys_o, x, p.u_trj_initial)
+    T = 25
+    xb = np.stack([np.tile([-1e4, -1e4, -1e4, -1e4, -0.3], (T + 1, 1)), np.tile([1e4, 1e4, 1e4, 1e4, 0.3], (T + 1, 1))])
+    ub = np.stack([np.full((T, 2), -2.0), np.full((T, 2), 2.0)])
+    xs, us = amd.solve_tvlqr(At, Bt, ct, p.Q, p.Qd, p.R, p.x0, p.xd_trj, amd.get_solver("osqp"),
+                             x_bound_abs=xb, u_bound_abs=ub, eps=1e-9)
+    assert np.abs(us).max() > 2.0 - 1e-6 or np.abs(xs[1:, 4]).max() > 0.3 - 1e-6       # something binds
+    res = orc.qp_box_kkt_residuals(At, Bt, ct, p.Q, p.Qd, p.R, p.x0, p.xd_trj, xb[0][0], xb[1][0], ub[0][0], ub[1][0],
+                                   xs, us, alpha_R=0.5)
+    assert max(res) < 1e-5, res
+    xu, uu = amd.solve_tvlqr(At, Bt, ct, p.Q, p.Qd, p.R, p.x0, p.xd_trj, None)
+    assert np.abs(uu - us).max() > 1e-2                                                  # and it matters
+    # ---- position-controlled form: the first tail QP of the planar hand's descent
+    from irs_mpc_amd import device as dev
+    T = 10
+    sys_d, sys_o2, x0, u_trj, x_trj, _, (A2, B2, c2), (Q, Qd, R, xd) = _hand_problem(amd, T, 300, 77)
+    idx = sys_o2.indices_u_into_x
+    rows = orc.quasistatic_bounds(x_trj, idx, None, np.array([-np.ones(4) * 0.05, np.ones(4) * 0.05]),
+                                  np.array([-np.ones(4) * 0.03, np.ones(4) * 0.03]))
+    xs3, us3 = amd.solve_tvlqr(A2, B2, c2, Q, Qd, R, x0, xd, None, indices_u_into_x=idx,
+                               u_bound_abs=np.stack([rows[2], rows[3]]), u_bound_rel=np.stack([rows[4], rows[5]]),
+                               rho=100.0, eps=1e-10, max_iter=40000)
+    # oracle: the same QP on the [x; u_prev] augmentation, solved by its ADMM
+    Ab, Bb, cb, Qb, Qdb, xdb = orc.quasistatic_augment(A2, B2, c2, Q, Qd, xd)
+    zlo = np.hstack([rows[0], np.vstack([np.full((1, 4), -np.inf), rows[2]])])
+    zhi = np.hstack([rows[1], np.vstack([np.full((1, 4), np.inf), rows[3]])])
+    F = orc.tvlqr_box_factor(Ab, Bb, cb, Qb, Qdb, R, zlo, zhi, rows[4], rows[5], 100.0, alpha_R=1.0)
+    z0 = np.concatenate([x0, x0[idx]])
+    zx, zu, _, it = orc.tvlqr_box_solve(F, Ab, Bb, cb, Qb, Qdb, xdb, z0, 0, zlo, zhi, rows[4], rows[5], None, 40000, 1e-10, 1.6)
+    np.testing.assert_allclose(xs3, zx[:, :7], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(us3, zx[1:, 7:], rtol=0, atol=1e-7)
+    assert np.abs(np.diff(np.vstack([x0[idx][None], us3]), axis=0)).max() <= 0.03 + 1e-7
+    with pytest.raises(NotImplementedError):
+        amd.solve_tvlqr(A2, B2, c2, Q, Qd, R, x0, xd, None, indices_u_into_x=[0, 1, 2, 3])
+
+
+def test_compute_least_squares_vs_reference_fixture(amd, golden_dir):
+    """IrsLqrZeroOrder.compute_least_squares stand-alone (irs_lqr_zero_order.py:27-36) on the device, against
+    the A_t, B_t the REFERENCE's own get_TV_matrices produced from the same samples (fixture generated by
+    running the reference: tests/golden/make_fixtures.py) and against numpy's SVD lstsq."""
+    d = np.load(os.path.join(golden_dir, "pendulum_zero_T30_N100.npz"))
+    sys_o = orc.PendulumOracle(float(d["h"]))
+    sol = amd.IrsLqrZeroOrder(amd.PendulumDynamics(float(d["h"])), pend_params(amd, 30), sampling=None)
+    for t in (0, 7, 29):
+        dx, du = d["dx"][t].astype(float), d["du"][t].astype(float)
+        X, U = d["x_trj"][t] + dx, d["u_trj"][t] + du
+        deltaf = sys_o.dynamics_batch(X, U) - sys_o.dynamics(d["x_trj"][t], d["u_trj"][t])
+        A, B = sol.compute_least_squares(np.hstack([dx, du]), deltaf)
+        np.testing.assert_allclose(A, d["At"][t], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(B, d["Bt"][t], rtol=1e-9, atol=1e-11)
+        ref = np.linalg.lstsq(np.hstack([dx, du]), deltaf, rcond=None)[0].T
+        np.testing.assert_allclose(np.hstack([A, B]), ref, rtol=1e-9, atol=1e-11)
+    with pytest.raises(ValueError):
+        sol.compute_least_squares(np.zeros((10, 3)), np.zeros((10, 2)))                    # rank deficient
 
 
 # ---------------------------------------------------------------- end to end vs the reference's result files
@@ -1009,6 +1076,68 @@ def test_capture_step_replays_the_two_launch_smoothing_step(amd):
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(got, out["o"][:3]))
     assert not torch.equal(got[1], ref[1])
+
+
+def test_collective_step_inside_the_library(amd):
+    """The multi-GPU smoothing step issued by the library itself (csrc/collective.hip): accumulate -> RCCL
+    all-reduce -> solve on one stream, eagerly and as ONE replayed HIP graph, with a communicator the library
+    owns (irs_comm_*; a 1-rank communicator on this one-GPU box: the all-reduce is the identity, the launch
+    sequence, the capture and the replay are the real ones).  Bit for bit equal to the two-stage path."""
+    from irs_mpc_amd import device as dev
+    from irs_mpc_amd._lib import SMOOTH_ZERO_ORDER_B
+    from irs_mpc_amd.distributed import CollectiveStep, DirectComm
+    T, N = 6, 3000
+    sys_d, sys_o, x0, u_trj = _hand_setup(amd, T)
+    x_trj = orc.rollout(sys_o, x0, u_trj)
+    du = (0.1 * np.random.default_rng(3).normal(size=(T, N, 4))).astype(np.float32)
+    dm = sys_d.dm()
+    xd, ud, dud = dev.to_dev(x_trj), dev.to_dev(u_trj), dev.to_dev(du, dev.F32)
+    sums = dm.smooth_accumulate(SMOOTH_ZERO_ORDER_B, xd, ud, None, dud).clone()
+    ws = dm._workspace(SMOOTH_ZERO_ORDER_B, T, N, xd.device)
+    A0, B0, c0, i0 = [t.clone() for t in dm.smooth_finalize(SMOOTH_ZERO_ORDER_B, N, xd, ud, sums, workspace=ws)]
+    comm = DirectComm()
+    assert comm.world == 1 and comm.handle.value
+    plan = dev.SmoothPlan(dm, SMOOTH_ZERO_ORDER_B, xd, ud, dx=None, du=dud, fuse=True, n_total=N)
+    step = CollectiveStep(plan, comm)
+    for label in ("eager", "graph"):
+        for k in ("At", "Bt", "ct"):
+            plan.out[k].zero_()
+        if label == "graph":
+            step.capture()
+        o = step.run()
+        torch.cuda.synchronize()
+        assert torch.equal(o["Bt"], B0) and torch.equal(o["ct"], c0) and torch.equal(o["At"], A0), label
+        assert torch.equal(plan.sums, sums), label
+        assert int(o["info"].abs().sum().item()) == 0
+    # the bare all-reduce entry point: identity on one rank
+    s2 = sums.clone()
+    comm.all_reduce_sums(s2)
+    torch.cuda.synchronize()
+    assert torch.equal(s2, sums)
+    step.destroy()
+    comm.destroy()
+
+
+@pytest.mark.timeout(600)
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """bench.py's N > 1 code path -- sharded samples, the all-reduce of the (T,P) sums inside every step, the
+    max-over-ranks timing, rank 0's single JSON line -- exercised with TWO ranks on this one GPU (gloo
+    collectives: RCCL refuses two ranks on one device), launched exactly as the driver launches N > 1."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29611", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "20", "--warmup", "3", "--rehearse-one-gpu", "--T", "12", "--N", "1500"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=560, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["N_total"] == 3000
+    assert out["value"] > 0 and out["ilqr_iters_per_s"] > 0
+    assert "all-reduce" in out["config"]["step"]
 
 
 def test_planar_hand_descent_runs(amd):
