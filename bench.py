@@ -395,6 +395,10 @@ def main():
                          "reference's semantics) or 50 over-relaxed projected sweeps + polish")
     ap.add_argument("--no-graph", action="store_true",
                     help="several ranks: issue the step's launches one by one instead of replaying a HIP graph")
+    ap.add_argument("--collective", default="torch", choices=["torch", "direct"],
+                    help="several ranks: the all-reduce through torch.distributed (default) or issued by the HIP "
+                         "library on a communicator it owns, the whole step captured into a HIP graph inside the "
+                         "library (csrc/collective.hip)")
     ap.add_argument("--force-unfused", action="store_true",
                     help="one GPU: time the multi-GPU step (accumulate + all-reduce + solve) with a 1-rank RCCL group")
     args = ap.parse_args()
@@ -511,6 +515,24 @@ def main():
 
             def smooth_step():
                 plan.run(stream)
+        elif args.collective == "direct":
+            # the library issues accumulate -> RCCL all-reduce -> solve itself and replays them as one HIP graph
+            from irs_mpc_amd.distributed import CollectiveStep, DirectComm
+            if "comm" not in step_info:
+                step_info["comm"] = DirectComm()
+            plan = dev.SmoothPlan(dm, MODE, x_trj, u_trj, dx=dx, du=du, fuse=True, n_total=n_total)
+            tv = plan.out
+            cstep = CollectiveStep(plan, step_info["comm"])
+            cstep.run()
+            torch.cuda.synchronize()
+            ref = [tv[k].clone() for k in ("At", "Bt", "ct")]
+            cstep.capture()
+            cstep.run()
+            torch.cuda.synchronize()
+            assert all(torch.equal(a_, tv[k]) for a_, k in zip(ref, ("At", "Bt", "ct"))), "replayed step differs"
+            step_info["graph"] = True
+            step_info["collective"] = "direct (library-owned RCCL communicator, graph captured in the library)"
+            smooth_step = cstep.run
         else:
             plan = dev.SmoothPlan(dm, MODE, x_trj, u_trj, dx=dx, du=du, fuse=False, n_total=n_total)
             tv = {}
@@ -752,6 +774,7 @@ def main():
                                  "accumulate launch + all-reduce + solve launch, issued one by one")
         if "graph_error" in step_info:
             out["config"]["graph_error"] = step_info["graph_error"]
+        out["config"]["collective"] = step_info.get("collective", "torch.distributed all_reduce (%s)" % args.backend)
     secondary = world == 1 and not unfused and not args.no_secondary
     if secondary:
         # north_star's N points for the timed workload

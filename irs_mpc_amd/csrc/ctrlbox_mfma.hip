@@ -380,21 +380,21 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
 #pragma unroll
             for (int r = 0; r < KA; ++r) P[r] = Pt[(size_t)(t_hi + 1) * L::PT + (r * 4 + rg) * NHP + col];
         }
-        double Fraw[5];
-        double acn[M], lon[M], hin[M], qn[KA];
-        auto load_step = [&](int t) {
-            load_F(t, Fraw);
+        // the prefetched data of a step (raw (A, B, c) elements, active set, bounds, -Qs sd entries): TWO sets that
+        // swap roles from step to step, two steps per loop trip -- nothing is copied at the back edge
+        struct Pre { double Fraw[5]; double ac[M], lo[M], hi[M], q[KA]; };
+        auto load_step = [&](int t, Pre& p) {
+            load_F(t, p.Fraw);
 #pragma unroll
             for (int j = 0; j < M; ++j) {
-                acn[j] = act_[(size_t)t * M + j];
-                lon[j] = lo_[(size_t)t * M + j];
-                hin[j] = hi_[(size_t)t * M + j];
+                p.ac[j] = act_[(size_t)t * M + j];
+                p.lo[j] = lo_[(size_t)t * M + j];
+                p.hi[j] = hi_[(size_t)t * M + j];
             }
 #pragma unroll
-            for (int r = 0; r < KA; ++r) qn[r] = qsd[(size_t)t * NR + qidx[r]];
+            for (int r = 0; r < KA; ++r) p.q[r] = qsd[(size_t)t * NR + qidx[r]];
         };
-        load_step(t_hi);
-        for (int t = t_hi; t >= t_lo; --t) {
+        auto bw_step = [&](int t, const Pre& cur, Pre& nxt, bool prefetch) {
 #ifdef IRS_CBM_STAMPS
             {   // how long the step waits for its prefetched (A, B, c)
                 const long long w0 = __builtin_amdgcn_s_memtime();
@@ -407,18 +407,18 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
 #endif
             v4d F;
             double Ba;
-            finish_F(Fraw, F, Ba);
+            finish_F(cur.Fraw, F, Ba);
             // active set and pinned values of this step (wave-uniform)
             double ac[M], bb[M];
 #pragma unroll
             for (int j = 0; j < M; ++j) {
-                ac[j] = acn[j];
-                bb[j] = acn[j] < 0.0 ? lon[j] : hin[j];
+                ac[j] = cur.ac[j];
+                bb[j] = cur.ac[j] < 0.0 ? cur.lo[j] : cur.hi[j];
             }
             v4d Lt = Lc;
 #pragma unroll
-            for (int r = 0; r < KA; ++r) Lt[r] = qhas[r] ? -qn[r] : Lc[r];
-            if (t > t_lo) load_step(t - 1);                   // prefetch
+            for (int r = 0; r < KA; ++r) Lt[r] = qhas[r] ? -cur.q[r] : Lc[r];
+            if (prefetch) load_step(t - 1, nxt);               // prefetch
             // D1 = P~ F ;  Theta = L_t + F' D1
             v4d D1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -555,7 +555,16 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
             }
             asm volatile("" :: "v"(P[0]));
             CBM_MARK(11);                                     // 3 MFMAs, masks, record stores
+        
+        };
+        Pre pa, pb;
+        load_step(t_hi, pa);
+        int t = t_hi;
+        for (; t - 1 >= t_lo; t -= 2) {
+            bw_step(t, pa, pb, true);
+            bw_step(t - 1, pb, pa, t - 2 >= t_lo);
         }
+        if (t >= t_lo) bw_step(t, pa, pb, false);
         rsync();
         CBM_ADD(0, t_hi - t_lo + 1);
     };

@@ -1826,6 +1826,75 @@ def test_planar_hand_full_size_properties(amd, mode_name):
         np.testing.assert_allclose(o_sub["Bt"][t].cpu().numpy(), Bo, rtol=0, atol=tol)
 
 
+def test_box_pivoting_full_size_properties(amd):
+    """BASELINE configs[4] at its FULL size on one GPU (box_pivoting, T=80, N=5*10^4: examples/box_pivoting/
+    run_box_pivoting.py:20-131 with the config's sample count): 8 logical shards -- the 8 GPUs of the config --
+    add up to the unsharded statistics; the solve of the summed shards equals the fused launch; launches are
+    bit-reproducible; the decoupled structure is exact; a 1 % subsample agrees with the NumPy oracle; and one
+    descent with the script's rate limit (u_bounds_rel = +-0.15 h, :119-120) at that size converges and is
+    self-consistent (its trajectory is the rollout of its controls, its cost their eval_cost)."""
+    from examples.run_quasistatic import box_problem
+    from irs_mpc_amd import device as dev
+    from irs_mpc_amd._lib import SMOOTH_ZERO_ORDER_B
+    from irs_mpc_amd.distributed import shard_range
+    T, N = 80, 50000
+    sys_d, x0, u_np, Q_dict, Qd_dict, R_dict, xd = box_problem(T)
+    sys_o = orc.BoxPivotOracle(0.1)
+    idx = sys_o.indices_u_into_x
+    x_np = orc.rollout(sys_o, x0, u_np)
+    dm = sys_d.dm()
+    x_trj, u_trj = dev.to_dev(x_np), dev.to_dev(u_np)
+    np.testing.assert_allclose(dm.rollout_cost(dev.to_dev(x0), u_trj, dev.to_dev(np.eye(5)), dev.to_dev(np.eye(2)),
+                                               dev.to_dev(xd))[0].cpu().numpy(), x_np, rtol=0, atol=1e-8)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    std = 0.1 ** 0.5                                               # :122-126 at iteration 1
+    du = std * torch.randn((T, N, 2), generator=g, device="cuda", dtype=torch.float32)
+    full = dm.smooth_accumulate(SMOOTH_ZERO_ORDER_B, x_trj, u_trj, None, du).clone()
+    acc = torch.zeros_like(full)
+    for r in range(8):
+        lo, hi = shard_range(N, r, 8)
+        acc += dm.smooth_accumulate(SMOOTH_ZERO_ORDER_B, x_trj, u_trj, None, du[:, lo:hi].contiguous())
+    scale = full.abs().max(dim=0).values + 1e-12
+    assert float(((acc - full).abs() / scale).max()) < 2e-5
+    A1, B1, c1, i1 = dm.smooth_finalize(SMOOTH_ZERO_ORDER_B, N, x_trj, u_trj, acc)
+    fused = dm.smooth(SMOOTH_ZERO_ORDER_B, x_trj, u_trj, None, du)
+    assert int(i1.abs().sum().item()) == 0 and int(fused["info"].abs().sum().item()) == 0
+    np.testing.assert_allclose(B1.cpu().numpy(), fused["Bt"].cpu().numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(c1.cpu().numpy(), fused["ct"].cpu().numpy(), rtol=0, atol=2e-5)
+    again = dm.smooth(SMOOTH_ZERO_ORDER_B, x_trj, u_trj, None, du)
+    assert torch.equal(again["Bt"], fused["Bt"]) and torch.equal(again["sums"], fused["sums"])
+    A_exp = np.eye(5)
+    A_exp[:, idx] = 0.0
+    assert np.array_equal(fused["At"].cpu().numpy(), np.tile(A_exp, (T, 1, 1)))
+    assert np.array_equal(fused["Bt"].cpu().numpy()[:, idx, :], np.tile(np.eye(2), (T, 1, 1)))
+    # a 1 % subsample against the oracle (three time steps: before, at and after the hand meets the box)
+    sub = du[:, :500].contiguous()
+    o_sub = dm.smooth(SMOOTH_ZERO_ORDER_B, x_trj, u_trj, None, sub)
+    for t in (0, 40, 79):
+        us = u_np[t] + sub[t].cpu().numpy().astype(np.float64)
+        fn = sys_o.dynamics_batch(np.tile(x_np[t], (500, 1)), us)
+        Bo = orc.zero_order_B_fit(sub[t].cpu().numpy().astype(np.float64), fn - sys_o.dynamics(x_np[t], u_np[t]))
+        Bo[idx, :] = np.eye(2)
+        np.testing.assert_allclose(o_sub["Bt"][t].cpu().numpy(), Bo, **FP32_TOL)
+    # one descent of the script at this size
+    Q, Qd, R = (dev.to_dev(sys_d.get_Q_from_Q_dict(Q_dict)), dev.to_dev(sys_d.get_Q_from_Q_dict(Qd_dict)),
+                dev.to_dev(sys_d.get_R_from_R_dict(R_dict)))
+    w = 0.15 * 0.1
+    out = dm.quasistatic_box_descent(fused["At"], fused["Bt"], fused["ct"], Q, Qd, R, dev.to_dev(xd), dev.to_dev(x0),
+                                     du_lo=dev.to_dev(np.full((T, 2), -w)), du_hi=dev.to_dev(np.full((T, 2), w)),
+                                     solver=0, max_iter=2000, eps=1e-9)
+    info = out["info"].cpu().numpy()
+    assert info[0] == 0 and info[2] == 0, info
+    xn, un = out["x_new"].cpu().numpy(), out["u_new"].cpu().numpy()
+    # the rate limit binds each tail's FIRST du, measured from the realised actuated position (tv_lqr.py:99-100)
+    assert np.abs(un - xn[:-1][:, idx]).max() <= w + 1e-8 and np.abs(un - xn[:-1][:, idx]).max() > w - 1e-6
+    x_roll = dm.rollout_cost(dev.to_dev(x0), dev.to_dev(un), Q, R, dev.to_dev(xd))[0].cpu().numpy()
+    np.testing.assert_allclose(xn, x_roll, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(float(out["cost"].item()),
+                               orc.eval_cost_quasistatic(xn, un, xd, Q.cpu().numpy(), Qd.cpu().numpy(), R.cpu().numpy(), idx),
+                               rtol=1e-10)
+
+
 def test_device_contact_qp_reproduces_reference_box_on_box(amd):
     """The device contact-QP code shared by every contact functor (csrc/contact_models.hpp:
     irs_contact_qp_step), on the reference's own 1-D example and against the closed form printed there

@@ -13,6 +13,13 @@ cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 200 --warmup 20 --no-cpu-baseline"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py $ARGS > $OUT/stats.log 2>&1
 echo "stats rc=$?"
+# per-workload stats passes: the average launch duration of each benchmarked kernel at ITS size
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_main -- python3 $R/bench.py $ARGS --no-secondary > $OUT/stats_main.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_first -- python3 $R/bench.py $ARGS --no-secondary --mode first_order > $OUT/stats_first.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_pgs -- python3 $R/bench.py $ARGS --no-secondary --contact-solver pgs > $OUT/stats_pgs.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_pendulum -- python3 $R/bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-secondary --workload pendulum > $OUT/stats_pendulum.log 2>&1
+echo "per-workload stats rc=$?"
+if [ "$2" = "stats-only" ]; then cd $R; python tools/pmc_summary.py $OUT $TAG > /dev/null; rm -rf $OUT/stats $OUT/stats_*/ ; exit 0; fi
 for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py $ARGS --no-secondary > $OUT/pmc_$C.log 2>&1
   echo "pass $C (planar_hand zero-order-B, exact step QP) rc=$?"
@@ -26,4 +33,4 @@ done
 cd $R
 python tools/pmc_summary.py $OUT $TAG
 # the raw traces are tens of MB (every launch is a row): keep only the summaries
-rm -rf $OUT/stats $OUT/pmc_*/
+rm -rf $OUT/stats $OUT/stats_*/ $OUT/pmc_*/
