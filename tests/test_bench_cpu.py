@@ -39,3 +39,20 @@ def test_flop_model_counts_per_sample_work_only():
     assert f_ex == 64 + 32 * 152 + 316 + 128 + 126 + 76 and "lower bound" in s_ex
     f1, _ = bench.contact_flops_per_sample("exact", 50, True)
     assert f1 - f_ex == 1208 - 76
+
+
+def test_adopted_profile_is_committed_and_stamped():
+    """bench.py quotes roofline.traffic / valu_issue_slots from profiles/pmc_latest.json: the file must name the
+    round profile it was adopted from, that profile's summaries must be under profiles/ (tracked), and the metric's
+    kernel must carry the counters the formulas use, with its average duration from the single-workload pass."""
+    import json
+    d = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+    meta = d["_meta"]
+    assert meta["commit"] and meta["tag"]
+    for suffix in ("_kernel_stats.csv", "_pmc_summary.json"):
+        assert os.path.exists(os.path.join(ROOT, "profiles", meta["tag"] + suffix)), suffix
+    e = d["planar_hand_exact_zeroB_T50_N10000"]
+    assert e["SQ_INSTS_VALU_raw_avg"] > 1e7 and e["FETCH_SIZE_raw_avg"] > 0 and e["WRITE_SIZE_raw_avg"] > 0
+    assert "single-workload" in e["kernel_avg_source"] and 5e4 < e["kernel_avg_ns"] < 2e5
+    slots = e["SQ_INSTS_VALU_raw_avg"] * 4 / 1024 / 2.4 / e["kernel_avg_ns"]
+    assert 0.2 < slots < 1.0, slots
