@@ -43,6 +43,10 @@ IRS_HD S irs_max0(const S& a) { return irs_value(a) > 0 ? a : S(a * (typename sc
 // std 0.3 the 90th percentile drops 10-40x.  Free: the factor is folded into 1 / W_ii.
 constexpr double kContactPgsOmega = 1.5;
 constexpr int kContactExactWarmSweeps = 32;    // projected sweeps that guess the active set of the exact solve
+#ifndef IRS_TRY_SWEEPS
+#define IRS_TRY_SWEEPS 32
+#endif
+constexpr int kContactTrySweeps = IRS_TRY_SWEEPS;   // ... of the sample pass's first attempt (irs_contact_qp_dual_exact_try)
 
 // 1/x: the hardware estimate (1 ulp) for f32 lanes, a true divide otherwise -- the dual active-set loop divides
 // 2 NC times per step, and a correctly rounded f32 divide is ~10 instructions
@@ -469,6 +473,119 @@ IRS_HD void irs_contact_qp_dual_exact(const T* Dinv, const T* b, const T (*J)[NX
     }
 }
 
+// FIRST ATTEMPT of the exact solve, for the sample pass (smooth.hip): the warm-up sweeps, ONE restricted solve
+// on the set they guess, and the optimality test -- no loop whose trip count depends on the data.  Returns true
+// when the guess IS the optimum (lam = the exact multipliers; ~90 % of the benchmark's samples); otherwise
+// `mask` holds the guess with the wrong-signed rows released, a valid `warm` argument for
+// irs_contact_qp_dual_exact, which finishes the sample.  Why two functions: inside one wave the data-dependent
+// part (repair rounds, active-set steps) runs as long as its slowest lane needs -- 1 lane in 20 takes a step,
+// every wave paid for two.  The sample pass therefore parks unfinished samples in a per-wave LDS queue and
+// finishes them 64 at a time, all lanes busy.  Same arithmetic as the first round of the full method, so a
+// sample that passes here gets the multipliers the full method would give it.
+template <typename T, int NX, int NC>
+IRS_HD bool irs_contact_qp_dual_exact_try(const T* Dinv, const T* b, const T (*J)[NX], const T* phi, T (*W)[NC],
+                                          T* lam, unsigned* mask) {
+    const T tol_rel = sizeof(T) == 4 ? T(1e-6) : T(1e-10);
+    const T piv_rel = sizeof(T) == 4 ? T(1e-5) : T(1e-7);
+    T g[NC], r[NC], Wd[NC], invw[NC];
+    bool act[NC];
+    {
+        T JD[NC][NX], Db[NX];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) Db[k] = b[k] * Dinv[k];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) JD[i][k] = J[i][k] * Dinv[k];
+            T ri = phi[i];
+#pragma unroll
+            for (int k = 0; k < NX; ++k) ri = ri - J[i][k] * Db[k];
+            g[i] = ri;
+            r[i] = ri;
+            lam[i] = T(0);
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                T w = JD[i][0] * J[j][0];
+#pragma unroll
+                for (int k = 1; k < NX; ++k) w = w + JD[i][k] * J[j][k];
+                W[i][j] = w;
+                W[j][i] = w;
+            }
+            Wd[i] = W[i][i];
+            invw[i] = T(kContactPgsOmega) * irs_rcp_fast(Wd[i]);
+        }
+    }
+    T scale = T(1e-30);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) scale = fmax(scale, fabs(r[i]));
+    const T tolv = tol_rel * scale;
+#pragma unroll 2
+    for (int sw = 0; sw < kContactTrySweeps; ++sw) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const T nw = fmax(lam[i] - g[i] * invw[i], T(0));
+            const T dl = nw - lam[i];
+            lam[i] = nw;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) g[j] = g[j] + W[j][i] * dl;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) act[i] = lam[i] > T(0);
+    // the restricted optimum on the guess: masked LDL' in row order (a dependent row leaves the guess)
+    T M_[NC][NC], inv[NC], y[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) M_[i][j] = W[i][j];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const T dj = M_[j][j];
+        const bool ok = act[j] && dj > piv_rel * Wd[j];
+        act[j] = ok;
+        inv[j] = ok ? irs_rcp_fast(dj) : T(0);
+#pragma unroll
+        for (int i = j + 1; i < NC; ++i) M_[j][i] = M_[i][j] * inv[j];
+#pragma unroll
+        for (int i = j + 1; i < NC; ++i)
+#pragma unroll
+            for (int k = j + 1; k <= i; ++k) M_[i][k] = M_[i][k] - M_[j][i] * M_[k][j];
+    }
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        T v = act[j] ? -r[j] : T(0);
+#pragma unroll
+        for (int k = 0; k < j; ++k) v = v - M_[k][j] * y[k];
+        y[j] = v;
+    }
+#pragma unroll
+    for (int j = NC - 1; j >= 0; --j) {
+        T v = y[j] * inv[j];
+#pragma unroll
+        for (int i = j + 1; i < NC; ++i) v = v - M_[j][i] * y[i];
+        y[j] = v;
+    }
+    bool good = true;
+    unsigned mk = 0u;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const bool neg = act[i] && !(y[i] > T(0));
+        good = good && !neg;
+        lam[i] = act[i] ? y[i] : T(0);
+        mk |= (act[i] && !neg) ? (1u << i) : 0u;
+    }
+    // slacks off the set: all >= -tol <=> optimal
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        T s = r[i];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) s = s + W[i][j] * lam[j];
+        good = good && (act[i] || s >= -tolv);
+    }
+    *mask = mk;
+    return good;
+}
+
 template <typename S, int NX, int NC>
 IRS_HD void irs_contact_qp_primal(const S* q, const typename scalar_of<S>::type* Dinv, const S* b,
                                   const S (*J)[NX], const S* lam, S* qn) {
@@ -611,11 +728,11 @@ IRS_HD void irs_contact_step(const ModelParams& p, const S* x_ext, const S* u, S
 // (lam_i W_ii > kContactActiveTol) -- diagnostics / tests only.
 template <class M, typename T, bool WITH_A>
 IRS_HD void irs_contact_step_grad(const ModelParams& p, const T* x_ext, const T* u, T* xn_ext, T* Bext, T* Aext,
-                                  unsigned* active_mask = nullptr) {
+                                  unsigned* active_mask = nullptr, unsigned* warm = nullptr) {
     constexpr int NX = M::NX, NC = M::NC, NU = M::NU;
     T q[NX], qn[NX], b[NX], J[NC][NX], phi[NC], Dinv[NX], W[NC][NC], lam[NC];
     const int iters = M::template assemble<T>(p, x_ext, u, q, Dinv, b, J, phi);
-    if constexpr (irs_contact_exact<M>::value) irs_contact_qp_dual_exact<T, NX, NC>(Dinv, b, J, phi, W, lam);
+    if constexpr (irs_contact_exact<M>::value) irs_contact_qp_dual_exact<T, NX, NC>(Dinv, b, J, phi, W, lam, warm);
     else irs_contact_qp_dual<T, NX, NC>(Dinv, b, J, phi, iters, W, lam);
     irs_contact_qp_primal<T, NX, NC>(q, Dinv, b, J, lam, qn);
     if (active_mask != nullptr) {

@@ -388,6 +388,15 @@ __device__ __forceinline__ void finalize_timestep(const ModelParams& p, const do
     if (lane == 0) info[t] = L.bad;
 }
 
+template <class Model, class = void>
+struct contact_rows_of { static constexpr int value = 0; };
+template <class Model>
+struct contact_rows_of<Model, std::void_t<decltype(Model::NC)>> { static constexpr int value = Model::NC; };
+template <class Model>
+constexpr int contact_rows() { return contact_rows_of<Model>::value; }
+
+constexpr int kDeferRing = 128;     // entries per wave: < 64 waiting + <= 64 new ones
+
 template <class Model, int MODE, bool RNG, bool FUSE, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
     using TR = SmoothTraits<Model, MODE>;
@@ -397,6 +406,15 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
     // matrix-core Gram path: zero-order, one 16-wide tile, too many statistics for registers
     constexpr bool USE_MFMA = MODE == IRS_SMOOTH_ZERO_ORDER_AB && d <= 16 && n <= 16 && TR::PP > 64 &&
                               BLOCK == kBlock;
+    // exact contact models in the lane path: unfinished samples wait in a per-wave ring (see the DEFER branch)
+    // Used by the u-only modes of the 8-row models (planar hand, T = 50: zero-order-B 102 -> 79 us at N = 1e4 and
+    // 820 -> 606 us at 1e5; first-order 112 -> 76 us).  Measured and left on the plain path: the 12-row box models --
+    // 39 % of their samples are unfinished after the first attempt, and W (144) + its factor live across the loop
+    // spill 200 VGPRs: 123 -> 225 us.
+    constexpr bool DEFER = irs_contact_exact<Model>::value && !USE_MFMA && MODE != IRS_SMOOTH_ZERO_ORDER_AB &&
+                           contact_rows<Model>() <= 8;
+    constexpr int QE = NZ + 1;
+    __shared__ float defer_ring[DEFER ? NW * kDeferRing * QE : 1];
     __shared__ float red[NW * TR::PP];
     __shared__ float tile[USE_MFMA ? NW * 64 * 36 : 1];
     __shared__ double red64[TR::NGRP * P];
@@ -498,6 +516,141 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
                 if (i < d && j == n) red[wave * TR::PP + TR::NH + i] = aH[r];
             }
         }
+    } else if constexpr (DEFER) {
+        // ---- exact contact models: finished samples accumulate at once, unfinished ones are parked ----------
+        // irs_contact_step_try (contact_models.hpp) settles ~90 % of the samples with straight-line code; the
+        // rest -- those whose guessed active set needs repair rounds or active-set steps, loops that run as long
+        // as a wave's slowest lane -- are parked in this wave's LDS ring (the perturbation + the warm set, NZ + 1
+        // dwords) and finished 64 at a time with every lane busy: as soon as 64 are waiting, and once more after
+        // the wave's last sample.  Everything is wave-private and in lane order (ballot prefix, wave-uniform
+        // head/tail): no barrier, no atomic, and the same sample lands in the same lane's accumulator in every
+        // run -- the fixed-order sums stay bit-reproducible.
+        float acc[TR::PP];
+#pragma unroll
+        for (int i = 0; i < TR::PP; ++i) acc[i] = 0.f;
+        const int lane = tid & 63, wave = tid >> 6;
+        float* ring = defer_ring + wave * (kDeferRing * QE);
+        int qhead = 0, qtail = 0;                           // wave-uniform
+        auto accumulate = [&](const float* z, const float* fx, const float* Bs, bool on) {
+            if constexpr (TR::FIRST_B) {
+#pragma unroll
+                for (int q = 0; q < n * m; ++q) acc[q] += on ? Bs[q] : 0.f;
+            } else {
+                float zz[NZ], df[n];
+#pragma unroll
+                for (int i = 0; i < NZ; ++i) zz[i] = on ? z[Z0 + i] : 0.f;
+#pragma unroll
+                for (int k = 0; k < n; ++k) df[k] = fx[k] - f0[k];
+                int q = 0;
+#pragma unroll
+                for (int i = 0; i < NZ; ++i)
+#pragma unroll
+                    for (int j = i; j < NZ; ++j) { acc[q] = fmaf(zz[i], zz[j], acc[q]); ++q; }
+#pragma unroll
+                for (int i = 0; i < NZ; ++i)
+#pragma unroll
+                    for (int k = 0; k < n; ++k) { acc[q] = fmaf(zz[i], df[k], acc[q]); ++q; }
+                if constexpr (TR::SUMZ) {
+#pragma unroll
+                    for (int i = 0; i < NZ; ++i) { acc[q] += zz[i]; ++q; }
+                }
+            }
+        };
+        // One loop, two kinds of trips (the choice is wave-uniform): a FRESH trip takes the wave's next 64 samples
+        // through the first attempt; a FLUSH trip takes up to 64 parked samples through the full method.  Both share
+        // the assembly of the step QP in front and the primal recovery / derivative / accumulation behind, so the
+        // kernel holds one copy of each (two complete inlined steps cost the first-order kernel 137 spilled VGPRs).
+        constexpr int NC = Model::NC;
+        int sb = s_begin + wave * 64;                       // wave-uniform
+        while (true) {
+            const bool fresh = sb < s_end;
+            const int pending = qtail - qhead;
+            const bool flush = pending >= 64 || (!fresh && pending > 0);
+            if (!fresh && !flush) break;
+            float z[d];
+            bool on;
+            unsigned wm = 0u;
+            int take = 0;
+            if (flush) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                take = min(64, pending);
+                on = lane < take;
+                const int slot = (qhead + (on ? lane : 0)) & (kDeferRing - 1);
+#pragma unroll
+                for (int i = 0; i < Z0; ++i) z[i] = 0.f;
+#pragma unroll
+                for (int i = 0; i < NZ; ++i) z[Z0 + i] = ring[slot * QE + i];
+                wm = __float_as_uint(ring[slot * QE + NZ]);
+            } else {
+                const int sidx = sb + lane;
+                on = sidx < s_end;
+                if constexpr (RNG) {
+                    constexpr int j0 = Z0 / 4;
+                    const unsigned long long gidx = a.sample_offset + (unsigned long long)sidx;
+#pragma unroll
+                    for (int j = j0; j < (d + 3) / 4; ++j) {
+                        float g[4];
+                        philox_normal4(gidx, (unsigned)t, (unsigned)j, a.iter, a.seed, g);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (4 * j + c < d) z[4 * j + c] = g[c] * a.std[4 * j + c];
+                    }
+#pragma unroll
+                    for (int i = 0; i < Z0; ++i) z[i] = 0.f;
+                } else {
+                    const size_t row = (size_t)t * a.N + (on ? sidx : s_end - 1);
+                    if constexpr (Z0 == 0) load_row<n>(a.dx + row * n, z);
+                    else {
+#pragma unroll
+                        for (int i = 0; i < n; ++i) z[i] = 0.f;
+                    }
+                    load_row<m>(a.du + row * m, z + n);
+                }
+            }
+            float xs[n], us[m], fx[n], Bs[TR::FIRST_B ? n * m : 1];
+#pragma unroll
+            for (int i = 0; i < n; ++i) xs[i] = xb[i] + z[i];
+#pragma unroll
+            for (int j = 0; j < m; ++j) us[j] = ub[j] + z[n + j];
+            float q[n], qn[n], bq[n], J[NC][n], phi[NC], Dinv[n], W[NC][NC], lam[NC];
+            Model::template assemble<float>(a.p, xs, us, q, Dinv, bq, J, phi);
+            bool fin_ = true;
+            if (flush) {
+                irs_contact_qp_dual_exact<float, n, NC>(Dinv, bq, J, phi, W, lam, &wm);
+                qhead += take;
+            } else {
+                unsigned mask = 0u;
+                fin_ = irs_contact_qp_dual_exact_try<float, n, NC>(Dinv, bq, J, phi, W, lam, &mask);
+                const bool hard = on && !fin_;
+                const unsigned long long bal = __ballot(hard);
+                if (hard) {
+                    const int slot = (qtail + __popcll(bal & ((1ull << lane) - 1ull))) & (kDeferRing - 1);
+#pragma unroll
+                    for (int i = 0; i < NZ; ++i) ring[slot * QE + i] = z[Z0 + i];
+                    ring[slot * QE + NZ] = __uint_as_float(mask);
+                }
+                qtail += __popcll(bal);
+                sb += BLOCK;
+            }
+            irs_contact_qp_primal<float, n, NC>(q, Dinv, bq, J, lam, qn);
+#pragma unroll
+            for (int k = 0; k < n; ++k) fx[Model::perm(k)] = qn[k];
+            if constexpr (TR::FIRST_B) {
+                int actc[m];
+#pragma unroll
+                for (int j = 0; j < m; ++j) actc[j] = Model::act(j);
+                float Bint[n][m], Aint[1][n];
+                irs_contact_qp_grad<float, n, NC, m, false>(Dinv, J, W, lam, actc, Bint, Aint);
+#pragma unroll
+                for (int k = 0; k < n; ++k)
+#pragma unroll
+                    for (int j = 0; j < m; ++j) Bs[Model::perm(k) * m + j] = Bint[k][j];
+            }
+            accumulate(z, fx, Bs, on && fin_);
+        }
+        block_reduce_lds<P, NW>(acc, red);
     } else {
         float acc[TR::PP];
 #pragma unroll

@@ -944,6 +944,37 @@ def test_first_order_contact_per_sample_classification(amd, system, std):
     np.testing.assert_allclose(o["Bt"].cpu().numpy()[0][free], Bs.mean(0)[free], rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("N", [50, 64, 130, 700, 5000, 60000])
+def test_parked_samples_are_finished_exactly_once(amd, N):
+    """The sample pass of the planar hand parks the samples its first attempt does not settle in a per-wave ring
+    and finishes them 64 at a time (smooth.hip, DEFER).  Whatever the split -- a partial wave, several waves, a
+    ring that fills and is flushed inside the loop (N = 60000: thousands of samples per wave at 8-40 % parked) --
+    the launch must equal the per-sample lanes (irs_contact_samples_f32, the undeferred full method): first-order
+    = their mean, zero-order-B = the least squares over their steps."""
+    from irs_mpc_amd import device as dev
+    from irs_mpc_amd._lib import SMOOTH_FIRST_ORDER, SMOOTH_ZERO_ORDER_B
+    sys_d, sys_o = amd.PlanarHandDynamics(0.1), orc.PlanarHandOracle(0.1)
+    x0 = HAND.pack([0.0, 0.35, 0.0], [-np.pi / 4, -np.pi / 4], [np.pi / 4, np.pi / 4])
+    x = orc.rollout(sys_o, x0, np.tile(x0[HAND_IDX], (25, 1)))[-1]           # the settled grasp: loaded contacts
+    idx = sys_o.indices_u_into_x
+    u, n, m = x[idx].copy(), sys_o.dim_x, sys_o.dim_u
+    free = np.setdiff1d(np.arange(n), idx)
+    du = (0.3 * np.random.default_rng(11).normal(size=(N, m))).astype(np.float32)
+    Xn, Bs, _ = sys_d.dm().contact_samples_f32(dev.to_dev(x), dev.to_dev(u), dev.to_dev(du, dev.F32))
+    Xn, Bs = Xn.cpu().numpy().astype(float), Bs.cpu().numpy().astype(float)
+    xs = dev.to_dev(np.stack([x, x]))
+    o1 = sys_d.dm().smooth(SMOOTH_FIRST_ORDER, xs, dev.to_dev(u[None]), None, dev.to_dev(du[None], dev.F32))
+    np.testing.assert_allclose(o1["Bt"].cpu().numpy()[0][free], Bs.mean(0)[free], rtol=0, atol=2e-6)
+    o2 = sys_d.dm().smooth(SMOOTH_ZERO_ORDER_B, xs, dev.to_dev(u[None]), None, dev.to_dev(du[None], dev.F32))
+    xf = x.astype(np.float32).astype(float)
+    Z = du.astype(float)
+    D = Xn - xf[None]
+    # the kernel's estimator: B = (Z'Z)^-1 (Z'D - sum(z) (f(x,u) - x)'), f(x,u) in f64
+    f0 = sys_o.dynamics(x, u) - xf
+    B2 = np.linalg.solve(Z.T @ Z, Z.T @ D - np.outer(Z.sum(0), f0)).T
+    np.testing.assert_allclose(o2["Bt"].cpu().numpy()[0][free], B2[free], rtol=0, atol=5e-6)
+
+
 def test_planar_hand_exact_contact_solver_vs_oracle(amd):
     """contact_solver="exact" (IRS_MODEL_PLANAR_HAND_EXACT): the device's dual active-set solve of the step QP
     == the oracle's (`pgs_iters = 0`) in f64 (dynamics, active-set Jacobian), and through the f32 sample
