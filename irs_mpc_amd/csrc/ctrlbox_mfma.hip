@@ -433,103 +433,117 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
             // lone wave pays ~5 cycles for EVERY instruction, and the step is instruction-bound.
             asm volatile("" :: "v"(Th[0]), "v"(Th[RN]));
             CBM_MARK(8);                                      // head + prefetch issue + 6 MFMAs
-            double H[M][M], gc[M], mf[M], bz[M];
-            // (staging these through an LDS tile instead -- 1 write, 16 broadcast + 4 strided reads -- was
-            // measured equal: the phase is bound by the count of f64 instructions, ~8 cycles each for a lone wave)
+            // A step whose m components are ALL pinned needs neither H nor its inverse: K~ = b e_h'.  (73 % of the
+            // backward steps of the trust-region benchmark: the re-swept stretch of a tail is its saturated head.)
+            bool allpin = true;
 #pragma unroll
-            for (int i = 0; i < M; ++i) {
+            for (int j = 0; j < M; ++j) allpin = allpin && ac[j] != 0.0;
+            double Kb = 0.0;
+            bool my_free = false;
+            if (__builtin_amdgcn_readfirstlane((int)allpin)) {
 #pragma unroll
-                for (int j = i; j < M; ++j) {
-                    H[i][j] = readlane_d(Th[RN], 16 * i + NHP + j);
-                    H[j][i] = H[i][j];
-                }
-                gc[i] = __shfl(Th[RN], 16 * i + col, 64);
-                mf[i] = ac[i] == 0.0 ? 1.0 : 0.0;
-                bz[i] = ac[i] == 0.0 ? 0.0 : bb[i];          // pinned value, 0 for a free component
-            }
-            asm volatile("" :: "v"(H[0][0]), "v"(gc[0]), "v"(gc[M - 1]));
-            CBM_MARK(9);                                      // gather of H and the lane's column
-            // Masked inverse: free rows/columns of H, identity on the pinned ones -- in CLOSED FORM (2 x 2 blocks:
-            // A^-1, the Schur complement S = C - B'A^-1 B, S^-1), not by an LDL' with substitutions.  A
-            // dependent f64 instruction of a lone wave costs ~32 cycles, an independent one ~8
-            // (tools/microbench/mfma_f64_latency.hip): the LDL' + two substitutions were a ~55-deep chain,
-            // ~1900 of the step's 2440 cycles; the block form is ~22 deep with plenty to issue beside it.
-            double Hm[M][M], Hi[M][M], y[M];
-#pragma unroll
-            for (int i = 0; i < M; ++i)
-#pragma unroll
-                for (int j = 0; j < M; ++j) Hm[i][j] = i == j ? (ac[i] == 0.0 ? H[i][i] : 1.0) : H[i][j] * (mf[i] * mf[j]);
-            bool spd = true;
-            auto inv2 = [&](double p, double q, double r, double& ip, double& iq, double& ir) {
-                // [p q; q r]^-1 = [r -q; -q p] / (p r - q^2)
-                const double det = fma(p, r, -q * q);
-                spd = spd && p > 0.0 && det > 0.0;
-                const double id = fast_rcp_m(det);
-                ip = r * id; iq = -q * id; ir = p * id;
-            };
-            if constexpr (M == 1) {
-                spd = Hm[0][0] > 0.0;
-                Hi[0][0] = fast_rcp_m(Hm[0][0]);
-            } else if constexpr (M == 2) {
-                inv2(Hm[0][0], Hm[0][1], Hm[1][1], Hi[0][0], Hi[0][1], Hi[1][1]);
-                Hi[1][0] = Hi[0][1];
+                for (int i = 0; i < M; ++i)
+                    if (i == rg) Kb = col == NS ? bb[i] : 0.0;
+                CBM_MARK(9);
             } else {
-                static_assert(M == 1 || M == 2 || M == 4, "closed-form inverse for 1, 2 or 4 controls");
-                double a0, a1, a2;                                   // A^-1 (symmetric: a0 a1; a1 a2)
-                inv2(Hm[0][0], Hm[0][1], Hm[1][1], a0, a1, a2);
-                // W = A^-1 B (2 x 2), S = C - B' W
-                const double w00 = fma(a0, Hm[0][2], a1 * Hm[1][2]), w01 = fma(a0, Hm[0][3], a1 * Hm[1][3]);
-                const double w10 = fma(a1, Hm[0][2], a2 * Hm[1][2]), w11 = fma(a1, Hm[0][3], a2 * Hm[1][3]);
-                const double s00 = Hm[2][2] - fma(Hm[0][2], w00, Hm[1][2] * w10);
-                const double s01 = Hm[2][3] - fma(Hm[0][2], w01, Hm[1][2] * w11);
-                const double s11 = Hm[3][3] - fma(Hm[0][3], w01, Hm[1][3] * w11);
-                double c0, c1, c2;                                   // S^-1
-                inv2(s00, s01, s11, c0, c1, c2);
-                // X = -W S^-1 (upper right), UL = A^-1 - X W'
-                const double x00 = -fma(w00, c0, w01 * c1), x01 = -fma(w00, c1, w01 * c2);
-                const double x10 = -fma(w10, c0, w11 * c1), x11 = -fma(w10, c1, w11 * c2);
-                Hi[0][0] = a0 - fma(x00, w00, x01 * w01);
-                Hi[0][1] = a1 - fma(x00, w10, x01 * w11);
-                Hi[1][1] = a2 - fma(x10, w10, x11 * w11);
-                Hi[1][0] = Hi[0][1];
-                Hi[0][2] = x00; Hi[0][3] = x01; Hi[1][2] = x10; Hi[1][3] = x11;
-                Hi[2][0] = x00; Hi[3][0] = x01; Hi[2][1] = x10; Hi[3][1] = x11;
-                Hi[2][2] = c0; Hi[2][3] = c1; Hi[3][2] = c1; Hi[3][3] = c2;
-            }
-            if (!spd && bad == 0) bad = t + 1;
-            const double hsel = col == NS ? 1.0 : 0.0;
-            double rhs[M];
-#pragma unroll
-            for (int i = 0; i < M; ++i) {
-                // right-hand side of the free rows: Theta_f,col + (homogeneous column) sum_p H_fp b_p
-                double hb0 = 0.0, hb1 = 0.0;
-#pragma unroll
-                for (int l = 0; l < M; ++l) {
-                    if (l & 1) hb1 = fma(H[i][l], bz[l], hb1);
-                    else hb0 = fma(H[i][l], bz[l], hb0);
+                double H[M][M], gc[M], mf[M], bz[M];
+                // (staging these through an LDS tile instead -- 1 write, 16 broadcast + 4 strided reads -- was
+                // measured equal: the phase is bound by the count of f64 instructions, ~8 cycles each for a lone wave)
+    #pragma unroll
+                for (int i = 0; i < M; ++i) {
+    #pragma unroll
+                    for (int j = i; j < M; ++j) {
+                        H[i][j] = readlane_d(Th[RN], 16 * i + NHP + j);
+                        H[j][i] = H[i][j];
+                    }
+                    gc[i] = __shfl(Th[RN], 16 * i + col, 64);
+                    mf[i] = ac[i] == 0.0 ? 1.0 : 0.0;
+                    bz[i] = ac[i] == 0.0 ? 0.0 : bb[i];          // pinned value, 0 for a free component
                 }
-                rhs[i] = fma(hsel, hb0 + hb1, gc[i]) * mf[i];
-            }
-#pragma unroll
-            for (int i = 0; i < M; ++i) {
-                double y0 = 0.0, y1 = 0.0;
-#pragma unroll
-                for (int l = 0; l < M; ++l) {
-                    if (l & 1) y1 = fma(Hi[i][l], rhs[l], y1);
-                    else y0 = fma(Hi[i][l], rhs[l], y0);
+                asm volatile("" :: "v"(H[0][0]), "v"(gc[0]), "v"(gc[M - 1]));
+                CBM_MARK(9);                                      // gather of H and the lane's column
+                // Masked inverse: free rows/columns of H, identity on the pinned ones -- in CLOSED FORM (2 x 2 blocks:
+                // A^-1, the Schur complement S = C - B'A^-1 B, S^-1), not by an LDL' with substitutions.  A
+                // dependent f64 instruction of a lone wave costs ~32 cycles, an independent one ~8
+                // (tools/microbench/mfma_f64_latency.hip): the LDL' + two substitutions were a ~55-deep chain,
+                // ~1900 of the step's 2440 cycles; the block form is ~22 deep with plenty to issue beside it.
+                double Hm[M][M], Hi[M][M], y[M];
+    #pragma unroll
+                for (int i = 0; i < M; ++i)
+    #pragma unroll
+                    for (int j = 0; j < M; ++j) Hm[i][j] = i == j ? (ac[i] == 0.0 ? H[i][i] : 1.0) : H[i][j] * (mf[i] * mf[j]);
+                bool spd = true;
+                auto inv2 = [&](double p, double q, double r, double& ip, double& iq, double& ir) {
+                    // [p q; q r]^-1 = [r -q; -q p] / (p r - q^2)
+                    const double det = fma(p, r, -q * q);
+                    spd = spd && p > 0.0 && det > 0.0;
+                    const double id = fast_rcp_m(det);
+                    ip = r * id; iq = -q * id; ir = p * id;
+                };
+                if constexpr (M == 1) {
+                    spd = Hm[0][0] > 0.0;
+                    Hi[0][0] = fast_rcp_m(Hm[0][0]);
+                } else if constexpr (M == 2) {
+                    inv2(Hm[0][0], Hm[0][1], Hm[1][1], Hi[0][0], Hi[0][1], Hi[1][1]);
+                    Hi[1][0] = Hi[0][1];
+                } else {
+                    static_assert(M == 1 || M == 2 || M == 4, "closed-form inverse for 1, 2 or 4 controls");
+                    double a0, a1, a2;                                   // A^-1 (symmetric: a0 a1; a1 a2)
+                    inv2(Hm[0][0], Hm[0][1], Hm[1][1], a0, a1, a2);
+                    // W = A^-1 B (2 x 2), S = C - B' W
+                    const double w00 = fma(a0, Hm[0][2], a1 * Hm[1][2]), w01 = fma(a0, Hm[0][3], a1 * Hm[1][3]);
+                    const double w10 = fma(a1, Hm[0][2], a2 * Hm[1][2]), w11 = fma(a1, Hm[0][3], a2 * Hm[1][3]);
+                    const double s00 = Hm[2][2] - fma(Hm[0][2], w00, Hm[1][2] * w10);
+                    const double s01 = Hm[2][3] - fma(Hm[0][2], w01, Hm[1][2] * w11);
+                    const double s11 = Hm[3][3] - fma(Hm[0][3], w01, Hm[1][3] * w11);
+                    double c0, c1, c2;                                   // S^-1
+                    inv2(s00, s01, s11, c0, c1, c2);
+                    // X = -W S^-1 (upper right), UL = A^-1 - X W'
+                    const double x00 = -fma(w00, c0, w01 * c1), x01 = -fma(w00, c1, w01 * c2);
+                    const double x10 = -fma(w10, c0, w11 * c1), x11 = -fma(w10, c1, w11 * c2);
+                    Hi[0][0] = a0 - fma(x00, w00, x01 * w01);
+                    Hi[0][1] = a1 - fma(x00, w10, x01 * w11);
+                    Hi[1][1] = a2 - fma(x10, w10, x11 * w11);
+                    Hi[1][0] = Hi[0][1];
+                    Hi[0][2] = x00; Hi[0][3] = x01; Hi[1][2] = x10; Hi[1][3] = x11;
+                    Hi[2][0] = x00; Hi[3][0] = x01; Hi[2][1] = x10; Hi[3][1] = x11;
+                    Hi[2][2] = c0; Hi[2][3] = c1; Hi[3][2] = c1; Hi[3][3] = c2;
                 }
-                y[i] = y0 + y1;
+                if (!spd && bad == 0) bad = t + 1;
+                const double hsel = col == NS ? 1.0 : 0.0;
+                double rhs[M];
+    #pragma unroll
+                for (int i = 0; i < M; ++i) {
+                    // right-hand side of the free rows: Theta_f,col + (homogeneous column) sum_p H_fp b_p
+                    double hb0 = 0.0, hb1 = 0.0;
+    #pragma unroll
+                    for (int l = 0; l < M; ++l) {
+                        if (l & 1) hb1 = fma(H[i][l], bz[l], hb1);
+                        else hb0 = fma(H[i][l], bz[l], hb0);
+                    }
+                    rhs[i] = fma(hsel, hb0 + hb1, gc[i]) * mf[i];
+                }
+    #pragma unroll
+                for (int i = 0; i < M; ++i) {
+                    double y0 = 0.0, y1 = 0.0;
+    #pragma unroll
+                    for (int l = 0; l < M; ++l) {
+                        if (l & 1) y1 = fma(Hi[i][l], rhs[l], y1);
+                        else y0 = fma(Hi[i][l], rhs[l], y0);
+                    }
+                    y[i] = y0 + y1;
+                }
+                // K~[rg][col] in B-operand layout (= K~' in A-operand layout): free rows -y, pinned rows b e_h'
+                // (y = 0 on a pinned row, bz = 0 on a free one)
+                double mfree = 0.0;
+    #pragma unroll
+                for (int i = 0; i < M; ++i) {
+                    const double kv = hsel * bz[i] - y[i];
+                    if (i == rg) { Kb = kv; mfree = mf[i]; }
+                }
+                if (rg >= M || col >= NH) Kb = 0.0;
+                my_free = mfree != 0.0;
             }
-            // K~[rg][col] in B-operand layout (= K~' in A-operand layout): free rows -y, pinned rows b e_h'
-            // (y = 0 on a pinned row, bz = 0 on a free one)
-            double Kb = 0.0, mfree = 0.0;
-#pragma unroll
-            for (int i = 0; i < M; ++i) {
-                const double kv = hsel * bz[i] - y[i];
-                if (i == rg) { Kb = kv; mfree = mf[i]; }
-            }
-            if (rg >= M || col >= NH) Kb = 0.0;
-            const bool my_free = mfree != 0.0;
             asm volatile("" :: "v"(Kb));
             CBM_MARK(10);                                     // inverse, right-hand sides, gains
             // D = Theta + Theta[:, nu] K~ ;  P~ = D + K~' Y, Y = rows of nu of D
