@@ -607,33 +607,50 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
             f.lo = lo_[(size_t)t * M + jj];
             f.hi = hi_[(size_t)t * M + jj];
         };
-        // one step: [s~+; out] = G_t s~ (KA chained MFMAs), outputs to the iterate / multiplier vectors
-        auto step = [&](int t, const Fw& f, const v4d& Sin, v4d& Sout) {
-            v4d Dn = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int s = 0; s < KA; ++s)
-                Dn = __builtin_amdgcn_mfma_f64_16x16x4f64(col < L::GR ? f.g[s] : 0.0, Sin[s], Dn, 0, 0, 0);
+        // one step: [s~+; out] = G_t s~ (KA chained MFMAs).  The outputs of step t (register RN of the result) are
+        // written out while the FIRST product of step t+1 is in flight: the select / store sequence is ~15 VALU
+        // instructions that would otherwise sit between two dependent matrix instructions of the chain.
+        struct Out { double ac, bd; int t; };
+        auto emit = [&](const Out& o, const v4d& Dp) {
             if (out_lane) {
-                const double o = Dn[RN];                       // K~_j s~ (free) or the multiplier Y_j s~ (pinned)
-                const double bd = f.ac < 0.0 ? f.lo : f.hi;
-                dst[(size_t)t * M + rg] = f.ac == 0.0 ? o : bd;
-                mu_[(size_t)t * M + rg] = f.ac == 0.0 ? 0.0 : o;
+                const double v = Dp[RN];                       // K~_j s~ (free) or the multiplier Y_j s~ (pinned)
+                dst[(size_t)o.t * M + rg] = o.ac == 0.0 ? v : o.bd;
+                mu_[(size_t)o.t * M + rg] = o.ac == 0.0 ? 0.0 : v;
             }
+        };
+        auto step = [&](int t, const Fw& f, const v4d& Sin, v4d& Sout, Out& prev, bool has_prev) {
+            v4d Dn = {0.0, 0.0, 0.0, 0.0};
+            Dn = __builtin_amdgcn_mfma_f64_16x16x4f64(col < L::GR ? f.g[0] : 0.0, Sin[0], Dn, 0, 0, 0);
+            if (has_prev) emit(prev, Sin);
+            prev.ac = f.ac;
+            prev.bd = f.ac < 0.0 ? f.lo : f.hi;
+            prev.t = t;
+#pragma unroll
+            for (int s = 1; s < KA; ++s)
+                Dn = __builtin_amdgcn_mfma_f64_16x16x4f64(col < L::GR ? f.g[s] : 0.0, Sin[s], Dn, 0, 0, 0);
             Sout = Dn;
         };
         // two steps per trip: the prefetched operands and the state tile alternate between two register sets,
         // so nothing is copied at the back edge (a lone wave pays ~5 cycles for every v_mov)
         Fw fa, fb;
         v4d S1;
+        Out po;
         fetch(t0, fa);
         int t = t0;
+        bool hp = false;
         for (; t + 1 < T; t += 2) {
             fetch(t + 1, fb);
-            step(t, fa, S, S1);
+            step(t, fa, S, S1, po, hp);
             if (t + 2 < T) fetch(t + 2, fa);
-            step(t + 1, fb, S1, S);
+            step(t + 1, fb, S1, S, po, true);
+            hp = true;
         }
-        if (t < T) step(t, fa, S, S1);
+        if (t < T) {
+            step(t, fa, S, S1, po, hp);
+            emit(po, S1);
+        } else if (hp) {
+            emit(po, S);
+        }
         rsync();
         CBM_ADD(2, T - t0);
     };
