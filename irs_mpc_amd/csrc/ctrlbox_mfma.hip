@@ -91,8 +91,9 @@ struct MfLayout {
     static __host__ __device__ size_t oV(int T) { return oP(T) + (size_t)(T + 1) * PT; }       // 6 x (T, M)
     static __host__ __device__ size_t oQ(int T) { return oV(T) + (size_t)6 * T * M; }          // (T+1, NR)
     static __host__ __device__ size_t rec_doubles(int T) { return oQ(T) + (size_t)(T + 1) * NR; }
-    // always in LDS: Qsym, Qdsym (NR^2), Rsym (M^2), sstart (NH), uctl (M), slack
-    static constexpr int small = 2 * NR * NR + M * M + NH + M + 16;
+    // always in LDS: Qsym, Qdsym (NR^2), Rsym (M^2), sstart (NH), uctl (M), slack, and 128 doubles the lanes that
+    // have nothing to write aim their stores at (forward sweep: unconditional stores, no exec-mask branch)
+    static constexpr int small = 2 * NR * NR + M * M + NH + M + 16 + 128;
 };
 
 // TWO waves, two roles.  Wave 0 solves the tail QPs (everything below up to the MPC loop); wave 1 is the
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
     double* Rsym = Qdsym + NR * NR;
     double* sstart = Rsym + M * M;                          // NH entries: s, then 1   (plant -> solver)
     double* uctl = sstart + NH;                             // M: the tail's first control, clipped (solver -> plant)
+    double* junk = uctl + M + 16;                           // 128 doubles nobody reads
 
     // orders this wave's memory traffic on the records: LDS executes one wave's operations in issue order
     // (compiler barrier only); global records additionally need the stores drained and this CU's L1 dropped
@@ -595,36 +597,35 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
                 S[s] = k < NH ? sstart[k] : 0.0;
             }
         }
-        const int jj = rg < M ? rg : 0;
         const int gofs = col < L::GR ? col : 0;
         const bool out_lane = col == 0 && rg < M;
-        struct Fw { double g[KA]; double ac, lo, hi; };
-        auto fetch = [&](int t, Fw& f) {
-            const double* G = Gt + (size_t)t * L::GT;
+        // What a step costs is its instruction count, not the latency of its three products: a lone wave issues in
+        // order, so only what stands BETWEEN two dependent matrix instructions runs in their shadow (64 cycles
+        // each), and an LDS or f64-compare instruction costs ~10 cycles there (measured: the chain alone 216 cycles
+        // per step, tools/microbench; the former loop body -- 6 reads, 2 compares, 8 selects, 2 masked writes, address
+        // adds -- 480).  The loop therefore only loads the tile and stores the RAW output row (register RN: K~_j s~
+        // of a free component, the multiplier Y_j s~ of a pinned one) into mu_; controls and multipliers are sorted
+        // out afterwards, four (t, j) entries per lane at once.
+        struct Fw { double g[KA]; };
+        const double* gp = Gt + (size_t)t0 * L::GT + (size_t)rg * L::GR + gofs;
+        auto fetch = [&](Fw& f) {
 #pragma unroll
-            for (int s = 0; s < KA; ++s) f.g[s] = G[(4 * s + rg) * L::GR + gofs];
-            f.ac = act_[(size_t)t * M + jj];
-            f.lo = lo_[(size_t)t * M + jj];
-            f.hi = hi_[(size_t)t * M + jj];
+            for (int s = 0; s < KA; ++s) f.g[s] = gp[4 * s * L::GR];
+            gp += L::GT;
         };
-        // one step: [s~+; out] = G_t s~ (KA chained MFMAs).  The outputs of step t (register RN of the result) are
-        // written out while the FIRST product of step t+1 is in flight: the select / store sequence is ~15 VALU
-        // instructions that would otherwise sit between two dependent matrix instructions of the chain.
-        struct Out { double ac, bd; int t; };
-        auto emit = [&](const Out& o, const v4d& Dp) {
-            if (out_lane) {
-                const double v = Dp[RN];                       // K~_j s~ (free) or the multiplier Y_j s~ (pinned)
-                dst[(size_t)o.t * M + rg] = o.ac == 0.0 ? v : o.bd;
-                mu_[(size_t)o.t * M + rg] = o.ac == 0.0 ? 0.0 : v;
-            }
+        // every lane stores (records in LDS): lanes without an output aim at `junk`, stride 0 -- a store under an
+        // exec-mask branch would make the count of outstanding LDS operations unknown to the compiler
+        double* mo = (out_lane || !LDSREC) ? mu_ + (size_t)t0 * M + (rg < M ? rg : 0) : junk + lane;
+        const int mstride = (out_lane || !LDSREC) ? M : 0;
+        auto emit = [&](const v4d& Dp) {
+            if constexpr (LDSREC) *mo = Dp[RN];
+            else if (out_lane) *mo = Dp[RN];
+            mo += mstride;
         };
-        auto step = [&](int t, const Fw& f, const v4d& Sin, v4d& Sout, Out& prev, bool has_prev) {
+        auto step = [&](const Fw& f, const v4d& Sin, v4d& Sout, bool has_prev) {
             v4d Dn = {0.0, 0.0, 0.0, 0.0};
             Dn = __builtin_amdgcn_mfma_f64_16x16x4f64(col < L::GR ? f.g[0] : 0.0, Sin[0], Dn, 0, 0, 0);
-            if (has_prev) emit(prev, Sin);
-            prev.ac = f.ac;
-            prev.bd = f.ac < 0.0 ? f.lo : f.hi;
-            prev.t = t;
+            if (has_prev) emit(Sin);                           // the previous step's outputs, in this product's shadow
 #pragma unroll
             for (int s = 1; s < KA; ++s)
                 Dn = __builtin_amdgcn_mfma_f64_16x16x4f64(col < L::GR ? f.g[s] : 0.0, Sin[s], Dn, 0, 0, 0);
@@ -634,22 +635,37 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
         // so nothing is copied at the back edge (a lone wave pays ~5 cycles for every v_mov)
         Fw fa, fb;
         v4d S1;
-        Out po;
-        fetch(t0, fa);
+        fetch(fa);
         int t = t0;
         bool hp = false;
+#ifdef IRS_CBM_STAMPS
+        const long long st_fl0 = __builtin_amdgcn_s_memtime();
+#endif
         for (; t + 1 < T; t += 2) {
-            fetch(t + 1, fb);
-            step(t, fa, S, S1, po, hp);
-            if (t + 2 < T) fetch(t + 2, fa);
-            step(t + 1, fb, S1, S, po, true);
+            fetch(fb);
+            step(fa, S, S1, hp);
+            if (t + 2 < T) fetch(fa);
+            step(fb, S1, S, true);
             hp = true;
         }
         if (t < T) {
-            step(t, fa, S, S1, po, hp);
-            emit(po, S1);
+            step(fa, S, S1, hp);
+            emit(S1);
         } else if (hp) {
-            emit(po, S);
+            emit(S);
+        }
+#ifdef IRS_CBM_STAMPS
+        asm volatile("" :: "v"(S[0]), "v"(S1[0]));
+        st_acc[13] += __builtin_amdgcn_s_memtime() - st_fl0;
+        st_acc[12] += 1;
+#endif
+        rsync();
+        // controls and multipliers from the raw rows
+        for (int q = t0 * M + lane; q < T * M; q += 64) {
+            const double raw = mu_[q], ac = act_[q];
+            const double bd = ac < 0.0 ? lo_[q] : hi_[q];
+            dst[q] = ac == 0.0 ? raw : bd;
+            mu_[q] = ac == 0.0 ? 0.0 : raw;
         }
         rsync();
         CBM_ADD(2, T - t0);
@@ -948,5 +964,6 @@ extern "C" void irs_cbm_print_stamps(void) {
                     "%lld tails; MPC loop %lld cyc; of backward: waiting for the prefetched step data %lld cyc\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
     fprintf(stderr, "[cbm stamps] backward step phases: head+6 MFMA %lld, gather %lld, inverse+gains %lld, 3 MFMA+stores %lld cyc\n",
             h[8], h[9], h[10], h[11]);
+    fprintf(stderr, "[cbm stamps] forward: %lld rollouts, %lld cyc inside their step loops\n", h[12], h[13]);
 }
 #endif
