@@ -433,6 +433,9 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
             // Theta_nu,: (rows NHP + i sit in register RN of lanes 16 i + col).
             // The active set enters as 0/1 factors mf_i (free) -- products instead of per-element selects: a
             // lone wave pays ~5 cycles for EVERY instruction, and the step is instruction-bound.
+            // (tried: __builtin_amdgcn_sched_group_barrier pipelines to spread the head's ~55 selects, compares and
+            // prefetch loads evenly over the gaps between the six products -- the scheduler piles them up behind the
+            // last one instead, because Theta accumulates into the registers P is read from: no change, 837 cycles)
             asm volatile("" :: "v"(Th[0]), "v"(Th[RN]));
             CBM_MARK(8);                                      // head + prefetch issue + 6 MFMAs
             // A step whose m components are ALL pinned needs neither H nor its inverse: K~ = b e_h'.  (73 % of the
