@@ -556,22 +556,40 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
             v4d Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(Kb, D[RN], D, 0, 0, 0);
             // closed loop A~cl = A~ + B~ K~ (off the chain of the next step)
             v4d Acl = __builtin_amdgcn_mfma_f64_16x16x4f64(Ba, Kb, F, 0, 0, 0);
+            // P~ for the next step.  Entries outside NH x NH (the nu rows and columns of the tile) are finite leftovers;
+            // as the A operand of the next step they only reach output rows >= NH, which nothing reads -- so no masking
+            // when the tile has no padding between s~ and nu (NH == NHP: both shipped models)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = rg + 4 * r;
-                P[r] = (r < KA && row < NH && col < NH) ? Pn[r] : 0.0;
+                if constexpr (NH == NHP) P[r] = r < KA ? Pn[r] : 0.0;
+                else P[r] = (r < KA && row < NH && col < NH) ? Pn[r] : 0.0;
             }
             // records: P~_t, and the forward tile G_t as its A-operand will be read -- element [i][k] belongs to
-            // register k >> 2 of lane (k & 3) * 16 + i, stored at k * GR + i
-            if (col < NHP) {
-#pragma unroll
-                for (int r = 0; r < KA; ++r) Pt[(size_t)t * L::PT + (r * 4 + rg) * NHP + col] = P[r];
-            }
+            // register k >> 2 of lane (k & 3) * 16 + i, stored at k * GR + i.  Records in LDS: every lane stores, the
+            // lanes outside the tile into `junk` (no exec-mask branches: see the forward sweep)
             double* G = Gt + (size_t)t * L::GT;
-            if (col < NH) {
+            if constexpr (LDSREC) {
+                double* pp = col < NHP ? Pt + (size_t)t * L::PT + (size_t)rg * NHP + col : junk + lane;
+                const int ps = col < NHP ? 4 * NHP : 0;
 #pragma unroll
-                for (int r = 0; r < KA; ++r) G[col * L::GR + (rg + 4 * r)] = Acl[r];        // (4 (col>>2) + (col&3)) = col
-                if (rg < M) G[col * L::GR + (NHP + rg)] = my_free ? Kb : D[RN];
+                for (int r = 0; r < KA; ++r) pp[r * ps] = P[r];
+                double* gq = col < NH ? G + (size_t)col * L::GR + rg : junk + 64 + lane;
+                const int gs = col < NH ? 4 : 0;
+#pragma unroll
+                for (int r = 0; r < KA; ++r) gq[r * gs] = Acl[r];
+                double* gk = (col < NH && rg < M) ? G + (size_t)col * L::GR + NHP + rg : junk + 64 + lane;
+                *gk = my_free ? Kb : D[RN];
+            } else {
+                if (col < NHP) {
+#pragma unroll
+                    for (int r = 0; r < KA; ++r) Pt[(size_t)t * L::PT + (r * 4 + rg) * NHP + col] = P[r];
+                }
+                if (col < NH) {
+#pragma unroll
+                    for (int r = 0; r < KA; ++r) G[col * L::GR + (rg + 4 * r)] = Acl[r];
+                    if (rg < M) G[col * L::GR + (NHP + rg)] = my_free ? Kb : D[RN];
+                }
             }
             asm volatile("" :: "v"(P[0]));
             CBM_MARK(11);                                     // 3 MFMAs, masks, record stores
