@@ -1,3 +1,5 @@
+"""Diagnostic: the sample pass of the exact contact models (parked samples, smooth.hip DEFER) against the per-sample
+lanes of irs_contact_samples_f32 at several N -- run on the GPU box:  gpurun -- python tools/probe_parked_samples.py"""
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
 import irs_mpc_amd as amd
