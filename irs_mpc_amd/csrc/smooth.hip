@@ -89,6 +89,8 @@ struct SmoothArgs {
     float* partial;    // (T, nblk, P)
     double* fnom;      // (T, n) f64 nominal steps written by workgroup 0 when chunk0 < chunk
     int chunk0;        // samples of workgroup 0 (== chunk unless it also evaluates the nominal step)
+    int wg0_rr;        // parked-sample kernels: trips of workgroup 0 dealt to all its waves; afterwards its last wave
+                       // (which evaluates the nominal step) sits out (INT_MAX: plain round robin)
     double* sums;      // (T, P) out
     // finalize outputs (fused path only)
     double* At;
@@ -395,6 +397,13 @@ struct contact_rows_of<Model, std::void_t<decltype(Model::NC)>> { static constex
 template <class Model>
 constexpr int contact_rows() { return contact_rows_of<Model>::value; }
 
+template <class Model, int MODE>
+constexpr bool defer_samples() {
+    return irs_contact_exact<Model>::value && MODE != IRS_SMOOTH_ZERO_ORDER_AB && contact_rows<Model>() <= 8;
+}
+// the f64 nominal step of workgroup 0 costs its wave about this many sample trips (parked-sample kernels)
+constexpr int kNominalTrips = 2;
+
 constexpr int kDeferRing = 128;     // entries per wave: < 64 waiting + <= 64 new ones
 
 template <class Model, int MODE, bool RNG, bool FUSE, int BLOCK>
@@ -411,8 +420,7 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
     // 820 -> 606 us at 1e5; first-order 112 -> 76 us).  Measured and left on the plain path: the 12-row box models --
     // 39 % of their samples are unfinished after the first attempt, and W (144) + its factor live across the loop
     // spill 200 VGPRs: 123 -> 225 us.
-    constexpr bool DEFER = irs_contact_exact<Model>::value && !USE_MFMA && MODE != IRS_SMOOTH_ZERO_ORDER_AB &&
-                           contact_rows<Model>() <= 8;
+    constexpr bool DEFER = defer_samples<Model, MODE>();
     constexpr int QE = NZ + 1;
     __shared__ float defer_ring[DEFER ? NW * kDeferRing * QE : 1];
     __shared__ float red[NW * TR::PP];
@@ -561,7 +569,15 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
         // the assembly of the step QP in front and the primal recovery / derivative / accumulation behind, so the
         // kernel holds one copy of each (two complete inlined steps cost the first-order kernel 137 spilled VGPRs).
         constexpr int NC = Model::NC;
-        int sb = s_begin + wave * 64;                       // wave-uniform
+        // trip k of wave w takes 64-sample block 4 k + w of the workgroup; in workgroup 0 the last wave sits out
+        // after a.wg0_rr trips (it evaluates the f64 nominal step instead) and the other three share the rest
+        int kt = 0;                                         // wave-uniform
+        const int rr = blk == 0 ? a.wg0_rr : 0x7fffffff;
+        auto block_of = [&](int k) {
+            if (k < rr) return NW * k + wave;
+            return wave == NW - 1 ? 0x3fffffff : NW * rr + (NW - 1) * (k - rr) + wave;
+        };
+        int sb = s_begin + 64 * block_of(0);
         while (true) {
             const bool fresh = sb < s_end;
             const int pending = qtail - qhead;
@@ -632,7 +648,9 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
                     ring[slot * QE + NZ] = __uint_as_float(mask);
                 }
                 qtail += __popcll(bal);
-                sb += BLOCK;
+                ++kt;
+                const int nb_ = block_of(kt);
+                sb = nb_ >= 0x3fffffff ? s_end : s_begin + 64 * nb_;
             }
             irs_contact_qp_primal<float, n, NC>(q, Dinv, bq, J, lam, qn);
 #pragma unroll
@@ -739,14 +757,16 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
     }
     if constexpr (NB) {
         // (a lone fused workgroup lets its solve evaluate the step itself: same cost, no round trip)
-        if (blk == 0 && (a.nblk > 1 || !FUSE) && tid < 64) {
+        constexpr int NOMW = DEFER ? NW - 1 : 0;           // the wave that evaluates it (parked-sample kernels: the one
+                                                           // that was dealt fewer sample trips)
+        if (blk == 0 && (a.nblk > 1 || !FUSE) && (tid >> 6) == NOMW) {
             double x64[n], u64[m], f64[n];
 #pragma unroll
             for (int i = 0; i < n; ++i) x64[i] = a.x_trj[(size_t)t * n + i];
 #pragma unroll
             for (int j = 0; j < m; ++j) u64[j] = a.u_trj[(size_t)t * m + j];
             Model::template step<double>(a.p, x64, u64, f64);
-            if (tid == 0) {
+            if ((tid & 63) == 0) {
 #pragma unroll
                 for (int i = 0; i < n; ++i)
                     __hip_atomic_store(a.fnom + (size_t)t * n + i, f64[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -988,6 +1008,16 @@ bool has_nominal_in_wg0(int model, int /*mode*/) {
     return r;
 }
 
+// smooth_kernel's DEFER path (defer_samples<Model, MODE>)
+bool uses_parked_samples(int model, int mode) {
+    bool r = false;
+    IRS_DISPATCH_MODEL(model, {
+        r = mode == IRS_SMOOTH_FIRST_ORDER ? defer_samples<Model, IRS_SMOOTH_FIRST_ORDER>()
+                                           : mode == IRS_SMOOTH_ZERO_ORDER_B ? defer_samples<Model, IRS_SMOOTH_ZERO_ORDER_B>() : false;
+    });
+    return r;
+}
+
 template <class Model>
 int sums_len_m(int mode) {
     switch (mode) {
@@ -1069,7 +1099,27 @@ int smooth_common(int model, const double* params, int n_params, int mode, int T
     a.T = T; a.N = N;
     plan_grid(T, N, is_light(model, mode), rng, &a.chunk, &a.nblk, &a.block, has_nominal_in_wg0(model, mode));
     a.chunk0 = a.chunk;
-    if (a.nblk >= 2 && a.block == kBlock && has_nominal_in_wg0(model, mode)) {
+    a.wg0_rr = 0x7fffffff;
+    bool planned = false;
+    if (a.nblk >= 2 && a.block == kBlock && uses_parked_samples(model, mode)) {
+        // parked-sample kernels balance by WAVE trips (64 samples): B blocks plus the nominal step's kNominalTrips
+        // over 4 nblk waves -> tt trips each; workgroup 0: tt - kNominalTrips rounds over its four waves, then
+        // kNominalTrips rounds over three.  (Chunks rounded to whole workgroup trips, as below, left three of the
+        // five workgroups of the benchmark's N = 1e4 with 9 trips and one with 5 + the nominal step.)
+        const int NW = kBlock / 64, B = (N + 63) / 64, nw = a.nblk * NW;
+        const int tt = (B + kNominalTrips + nw - 1) / nw, rr = tt - kNominalTrips;
+        if (rr >= 1) {
+            const int c0b = NW * rr + (NW - 1) * kNominalTrips;
+            const int restb = B > c0b ? (B - c0b + (a.nblk - 1) - 1) / (a.nblk - 1) : 0;
+            if (restb <= NW * tt) {
+                a.chunk0 = c0b * 64;
+                a.chunk = restb > 0 ? restb * 64 : 64;
+                a.wg0_rr = rr;
+                planned = true;
+            }
+        }
+    }
+    if (!planned && a.nblk >= 2 && a.block == kBlock && has_nominal_in_wg0(model, mode)) {
         // workgroup 0 gives up kNominalCost samples per lane and evaluates the f64 nominal step
         int c0 = a.chunk - kNominalCost * kBlock;
         if (c0 < kBlock) c0 = kBlock;
