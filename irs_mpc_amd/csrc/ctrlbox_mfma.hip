@@ -83,13 +83,13 @@ template <int NR, int M>
 struct MfLayout {
     static constexpr int NS = NR + M, NH = NS + 1, NHP = (NH + 3) / 4 * 4, KA = NHP / 4;
     static constexpr bool FITS = NHP + M <= 16 && M <= 4;
-    // doubles per time step: forward tile image, P~ image (lanes with col < NHP), 6 control vectors, Qs sd
+    // doubles per time step: forward tile image, P~ image (lanes with col < NHP), 7 control vectors, -Qs sd
     // (the forward tile keeps its rows i < NHP + M only: index (4 s + k-group) * GR + i)
     static constexpr int GR = NHP + M, GT = KA * 4 * GR, PT = KA * 4 * NHP;
     static __host__ __device__ size_t oG(int) { return 0; }
     static __host__ __device__ size_t oP(int T) { return (size_t)T * GT; }
-    static __host__ __device__ size_t oV(int T) { return oP(T) + (size_t)(T + 1) * PT; }       // 6 x (T, M)
-    static __host__ __device__ size_t oQ(int T) { return oV(T) + (size_t)6 * T * M; }          // (T+1, NR)
+    static __host__ __device__ size_t oV(int T) { return oP(T) + (size_t)(T + 1) * PT; }       // 7 x (T, M)
+    static __host__ __device__ size_t oQ(int T) { return oV(T) + (size_t)7 * T * M; }          // (T+1, NR)
     static __host__ __device__ size_t rec_doubles(int T) { return oQ(T) + (size_t)(T + 1) * NR; }
     // always in LDS: Qsym, Qdsym (NR^2), Rsym (M^2), sstart (NH), uctl (M), slack, and 128 doubles the lanes that
     // have nothing to write aim their stores at (forward sweep: unconditional stores, no exec-mask branch)
@@ -143,6 +143,7 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
     double* uu_ = Vv + (size_t)3 * T * M;
     double* us_ = Vv + (size_t)4 * T * M;
     double* mu_ = Vv + (size_t)5 * T * M;
+    double* bnd_ = Vv + (size_t)6 * T * M;                 // the bound a pinned component sits at (follows act_)
     double* qsd = rec + L::oQ(T);
     double* Qsym = sm;
     double* Qdsym = Qsym + NR * NR;
@@ -276,13 +277,14 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
         double a0 = a.act_io ? a.act_io[q] : 0.0;
         a0 = a0 < 0.0 ? (lo > -INF ? -1.0 : 0.0) : (a0 > 0.0 ? (hi < INF ? 1.0 : 0.0) : 0.0);
         act_[q] = a0;
+        bnd_[q] = a0 < 0.0 ? lo : hi;
         uu_[q] = 0.0; us_[q] = 0.0; mu_[q] = 0.0;
     }
     for (int q = lane; q < (T + 1) * NR; q += 64) {
         const int t = q / NR, i = q % NR;
         double s = 0.0;
         for (int j = 0; j < NR; ++j) s += Qsym[i * NR + j] * a.xd[(size_t)t * NR + j];
-        qsd[q] = s;                                         // (Qs sd_t)[:NR]; the w block of sd is zero
+        qsd[q] = -s;                                        // -(Qs sd_t)[:NR] (the tile's linear entries); the w block of sd is zero
     }
     for (size_t q = lane; q < (size_t)T * L::GT; q += 64) Gt[q] = 0.0;      // unwritten image entries stay zero
     // stage-cost tile without its time-varying column, in C/D layout (row = rg + 4 r, col)
@@ -385,14 +387,13 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
         }
         // the prefetched data of a step (raw (A, B, c) elements, active set, bounds, -Qs sd entries): TWO sets that
         // swap roles from step to step, two steps per loop trip -- nothing is copied at the back edge
-        struct Pre { double Fraw[5]; double ac[M], lo[M], hi[M], q[KA]; };
+        struct Pre { double Fraw[5]; double ac[M], bd[M], q[KA]; };
         auto load_step = [&](int t, Pre& p) {
             load_F(t, p.Fraw);
 #pragma unroll
             for (int j = 0; j < M; ++j) {
                 p.ac[j] = act_[(size_t)t * M + j];
-                p.lo[j] = lo_[(size_t)t * M + j];
-                p.hi[j] = hi_[(size_t)t * M + j];
+                p.bd[j] = bnd_[(size_t)t * M + j];
             }
 #pragma unroll
             for (int r = 0; r < KA; ++r) p.q[r] = qsd[(size_t)t * NR + qidx[r]];
@@ -416,11 +417,11 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
 #pragma unroll
             for (int j = 0; j < M; ++j) {
                 ac[j] = cur.ac[j];
-                bb[j] = cur.ac[j] < 0.0 ? cur.lo[j] : cur.hi[j];
+                bb[j] = cur.bd[j];
             }
             v4d Lt = Lc;
 #pragma unroll
-            for (int r = 0; r < KA; ++r) Lt[r] = qhas[r] ? -cur.q[r] : Lc[r];
+            for (int r = 0; r < KA; ++r) Lt[r] = qhas[r] ? cur.q[r] : Lc[r];
             if (prefetch) load_step(t - 1, nxt);               // prefetch
             // D1 = P~ F ;  Theta = L_t + F' D1
             v4d D1 = {0.0, 0.0, 0.0, 0.0};
@@ -684,7 +685,7 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
         // controls and multipliers from the raw rows
         for (int q = t0 * M + lane; q < T * M; q += 64) {
             const double raw = mu_[q], ac = act_[q];
-            const double bd = ac < 0.0 ? lo_[q] : hi_[q];
+            const double bd = bnd_[q];
             dst[q] = ac == 0.0 ? raw : bd;
             mu_[q] = ac == 0.0 ? 0.0 : raw;
         }
@@ -724,7 +725,10 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
                 const double lo = lo_[(size_t)t * M + j], hi = hi_[(size_t)t * M + j];
                 const double c = fmin(fmax(v, lo), hi);
                 dlt[j] = c - v;
-                if (lane == 0) act_[(size_t)t * M + j] = v < lo - tol_ ? -1.0 : (v > hi + tol_ ? 1.0 : 0.0);
+                if (lane == 0) {
+                    act_[(size_t)t * M + j] = v < lo - tol_ ? -1.0 : (v > hi + tol_ ? 1.0 : 0.0);
+                    bnd_[(size_t)t * M + j] = v < lo - tol_ ? lo : hi;
+                }
             }
             // s~+ rows (column 0): x rows += B delta, w rows += delta
             if (col == 0) {
@@ -791,7 +795,7 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
                 } else {
                     if (mu > tol) nw = 0.0;
                 }
-                if (nw != ac) { act_[q] = nw; chg = max(chg, q / M); }
+                if (nw != ac) { act_[q] = nw; bnd_[q] = nw < 0.0 ? lo_[q] : hi_[q]; chg = max(chg, q / M); }
             }
             chg = wmax_i(chg);
             rsync();
@@ -806,7 +810,7 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
                 const double u = fmin(fmax(uu_[q], lo), hi);
                 uu_[q] = u;
                 const double nw = u <= lo ? -1.0 : (u >= hi ? 1.0 : 0.0);
-                if (nw != act_[q]) { act_[q] = nw; chg = max(chg, q / M); }
+                if (nw != act_[q]) { act_[q] = nw; bnd_[q] = nw < 0.0 ? lo : hi; chg = max(chg, q / M); }
             }
             chg = wmax_i(chg);
             rsync();
@@ -836,6 +840,7 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
                         if (q == qb) {
                             act_[q] = d > 0.0 ? 1.0 : -1.0;
                             uu_[q] = d > 0.0 ? hi_[q] : lo_[q];
+                            bnd_[q] = uu_[q];
                         } else {
                             uu_[q] = u + alpha * d;
                         }
