@@ -26,7 +26,7 @@
 // multipliers (rows NHP..) together.  The state never leaves the registers.
 //
 // Per-step records (G_t image, P~_t, active set, bounds, iterates) live in LDS when the horizon fits
-// (planar hand: T <= 54; box pivoting: T <= 125) and otherwise in a caller-supplied global workspace
+// (planar hand: T <= 53; box pivoting: T <= 123) and otherwise in a caller-supplied global workspace
 // (L2-resident; same code, slower) -- the reference has no horizon limit (irs_lqr_quasistatic.py:325-345).
 // f64 matrix and vector rates are equal on gfx950: what the tile buys is not flops but the absence of
 // LDS round trips and cross-lane traffic inside a step (ctrlbox.hip: 6 LDS phases, ~7000 cycles per
