@@ -1091,6 +1091,147 @@ struct BoxPushExactModel : BoxPushModel {
     }
 };
 
+// ---- a step along a trajectory in TWO phases, for a caller that learns x_t before u_t ----------------------------
+// The plant wave of the descent kernels (ctrlbox_mfma.hip, ctrlbox.hip) knows the realised state as soon as its
+// previous step is done, but the control only when the solver wave has finished the tail -- and it idles in between.
+// Everything of the step QP that depends on x alone is therefore prepared while the solver works: the contact
+// geometry (J, phi), W = J D^-1 J' and its masked factorisation on the previous step's active set.  Once u arrives,
+// the linear term, ONE pair of substitutions, the optimality test and the primal recovery remain (about a third of
+// the step).  If the prepared set is not the optimal one (a contact made or broken), the step falls back to the full
+// method, warm-started as before: the answer is the same either way.
+// Only the actuated entries of b depend on u: b_a = (q_a - u_j) / Dinv_a (every contact model here: an impedance-
+// controlled joint contributes K (q_a - u) with D_aa = K; irs_contact_qp_grad relies on the same structure).
+template <class M>
+struct irs_step_prepared {
+    static constexpr int NX = M::NX, NC = M::NC;
+    double q[NX], Dinv[NX], b0[NX], J[NC][NX], phi[NC], Mf[NC][NC], inv[NC];
+    bool act[NC], ok;
+};
+
+template <class M>
+IRS_HD void irs_step_along_prepare(const ModelParams& p, const double* x, unsigned warm, irs_step_prepared<M>& pre) {
+    if constexpr (irs_contact_exact<M>::value) {
+        constexpr int NX = M::NX, NC = M::NC, NU = M::NU;
+        const double piv_rel = 1e-7;
+        double u0[NU];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) u0[j] = x[M::u_into_x(j)];          // b0 of the actuated rows = 0
+        M::template assemble<double>(p, x, u0, pre.q, pre.Dinv, pre.b0, pre.J, pre.phi);
+        pre.ok = warm != ~0u;
+        double Wd[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            pre.act[i] = ((warm >> i) & 1u) != 0u && pre.ok;
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                double w = pre.J[i][0] * pre.Dinv[0] * pre.J[j][0];
+#pragma unroll
+                for (int k = 1; k < NX; ++k) w = w + pre.J[i][k] * pre.Dinv[k] * pre.J[j][k];
+                pre.Mf[i][j] = w;
+            }
+            Wd[i] = pre.Mf[i][i];
+        }
+        // masked LDL' in row order (unit lower factor kept in the upper triangle), as in irs_contact_qp_dual_exact
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const double dj = pre.Mf[j][j];
+            const bool ok = pre.act[j] && dj > piv_rel * Wd[j];
+            pre.act[j] = ok;
+            pre.inv[j] = ok ? irs_rcp_fast(dj) : 0.0;
+#pragma unroll
+            for (int i = j + 1; i < NC; ++i) pre.Mf[j][i] = pre.Mf[i][j] * pre.inv[j];
+#pragma unroll
+            for (int i = j + 1; i < NC; ++i)
+#pragma unroll
+                for (int k = j + 1; k <= i; ++k) pre.Mf[i][k] = pre.Mf[i][k] - pre.Mf[j][i] * pre.Mf[k][j];
+        }
+    }
+}
+
+template <class M>
+IRS_HD void irs_step_along_finish(const ModelParams& p, const double* x, const double* u, const irs_step_prepared<M>& pre,
+                                  double* xn, unsigned* warm) {
+    if constexpr (irs_contact_exact<M>::value) {
+        constexpr int NX = M::NX, NC = M::NC, NU = M::NU;
+        bool good = pre.ok;
+        double b[NX], lam[NC];
+        if (pre.ok) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) b[k] = pre.b0[k];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) b[M::act(j)] = (pre.q[M::act(j)] - u[j]) / pre.Dinv[M::act(j)];
+            double r[NC], y[NC], Db[NX];
+#pragma unroll
+            for (int k = 0; k < NX; ++k) Db[k] = b[k] * pre.Dinv[k];
+            double scale = 1e-30;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                double ri = pre.phi[i];
+#pragma unroll
+                for (int k = 0; k < NX; ++k) ri = ri - pre.J[i][k] * Db[k];
+                r[i] = ri;
+                scale = fmax(scale, fabs(ri));
+            }
+            const double tolv = 1e-10 * scale;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                double v = pre.act[j] ? -r[j] : 0.0;
+#pragma unroll
+                for (int k = 0; k < j; ++k) v = v - pre.Mf[k][j] * y[k];
+                y[j] = v;
+            }
+#pragma unroll
+            for (int j = NC - 1; j >= 0; --j) {
+                double v = y[j] * pre.inv[j];
+#pragma unroll
+                for (int i = j + 1; i < NC; ++i) v = v - pre.Mf[j][i] * y[i];
+                y[j] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                good = good && !(pre.act[i] && !(y[i] > 0.0));
+                lam[i] = pre.act[i] ? y[i] : 0.0;
+            }
+            // slacks off the set, through J (W itself is not kept): s = r + J D^-1 J' lam
+            double v[NX];
+#pragma unroll
+            for (int k = 0; k < NX; ++k) {
+                double f = 0.0;
+#pragma unroll
+                for (int i = 0; i < NC; ++i) f = f + pre.J[i][k] * lam[i];
+                v[k] = f * pre.Dinv[k];
+            }
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                double sl = r[i];
+#pragma unroll
+                for (int k = 0; k < NX; ++k) sl = sl + pre.J[i][k] * v[k];
+                good = good && (pre.act[i] || sl >= -tolv);
+            }
+        }
+        if (irs_wave_all<double>(good)) {
+            double qn[NX];
+#pragma unroll
+            for (int k = 0; k < NX; ++k) {
+                double f = -b[k];
+#pragma unroll
+                for (int i = 0; i < NC; ++i) f = f + pre.J[i][k] * lam[i];
+                qn[k] = pre.q[k] + f * pre.Dinv[k];
+            }
+#pragma unroll
+            for (int k = 0; k < NX; ++k) xn[M::perm(k)] = qn[k];
+            unsigned mk = 0u;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) mk |= pre.act[i] ? (1u << i) : 0u;
+            *warm = mk;
+        } else {
+            irs_contact_step<M, double>(p, x, u, xn, warm);
+        }
+    } else {
+        M::template step<double>(p, x, u, xn);
+    }
+}
+
 // One f64 step along a TRAJECTORY: models whose step QP is solved exactly take the previous step's active set
 // as the starting guess of this one (`warm`: ~0u before the first step); every other model just steps.
 template <class Model>

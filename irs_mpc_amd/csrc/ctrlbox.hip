@@ -164,10 +164,14 @@ __global__ __launch_bounds__(128) void ctrlbox_descent_kernel(BoxArgs a) {
         };
         double cost = 0.0;
         unsigned warm = ~0u;                                // active set of the previous contact step
+        irs_step_prepared<Model> pre;
         wg_barrier();                                       // S0
         publish_start();
         for (int tau = 0; tau < T; ++tau) {
             wg_barrier();                                   // A(tau)
+            // while the solver wave works on this tail: everything of the coming contact step that depends on the
+            // state alone (contact_models.hpp, irs_step_along_prepare)
+            irs_step_along_prepare<Model>(a.p, xr, warm, pre);
             wg_barrier();                                   // B(tau)
 #pragma unroll
             for (int j = 0; j < M; ++j) ur[j] = KIND == KIND_ABS ? uctl[j] : ub[j] + uctl[j];
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(128) void ctrlbox_descent_kernel(BoxArgs a) {
                 for (int j = 0; j < M; ++j) dv[j] = ur[j] - (tau == 0 ? ub[j] : up[j]);
                 cost += quad(Qsym, e, NR) + quad(Rsym, dv, M);
             }
-            irs_step_along<Model>(a.p, xr, ur, xn, &warm);
+            irs_step_along_finish<Model>(a.p, xr, ur, pre, xn, &warm);
 #pragma unroll
             for (int i = 0; i < NR; ++i) xr[i] = xn[i];
 #pragma unroll

@@ -211,34 +211,46 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
         };
         double cost = 0.0;
         unsigned warm = ~0u;                                // active set of the previous contact step
+        irs_step_prepared<Model> pre;
         wg_barrier();                                       // S0
         publish_start();
+        // The solver wave waits for this wave at A(tau+1): between B(tau) and that barrier stands only what the next
+        // start state needs (the u-dependent rest of the contact step).  The bookkeeping of step tau -- its share of
+        // IrsLqrQuasistatic.eval_cost (irs_lqr_quasistatic.py:153-194), the stores of x_new / u_new -- and the
+        // state-only part of step tau+1 happen after A(tau+1), while the solver works.
+        double xs[NR], dv[M];
+        auto book = [&](int tau) {
+            double e[NR];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) e[i] = xs[i] - a.xd[(size_t)tau * NR + i];
+            cost += quad(Qsym, e, NR) + quad(Rsym, dv, M);
+            if (lane == 0) {
+#pragma unroll
+                for (int j = 0; j < M; ++j) a.u_new[(size_t)tau * M + j] = up[j];
+#pragma unroll
+                for (int i = 0; i < NR; ++i) a.x_new[(size_t)(tau + 1) * NR + i] = xr[i];
+            }
+        };
         for (int tau = 0; tau < T; ++tau) {
             wg_barrier();                                   // A(tau)
+            if (tau > 0) book(tau - 1);
+            // everything of the coming contact step that depends on the state alone (contact_models.hpp)
+            irs_step_along_prepare<Model>(a.p, xr, warm, pre);
             wg_barrier();                                   // B(tau): uctl holds the tail's first control
 #pragma unroll
             for (int j = 0; j < M; ++j) ur[j] = KIND == KIND_ABS_M ? uctl[j] : ub[j] + uctl[j];
-            {   // IrsLqrQuasistatic.eval_cost (irs_lqr_quasistatic.py:153-194)
-                double e[NR], dv[M];
 #pragma unroll
-                for (int i = 0; i < NR; ++i) e[i] = xr[i] - a.xd[(size_t)tau * NR + i];
+            for (int j = 0; j < M; ++j) dv[j] = ur[j] - (tau == 0 ? ub[j] : up[j]);
 #pragma unroll
-                for (int j = 0; j < M; ++j) dv[j] = ur[j] - (tau == 0 ? ub[j] : up[j]);
-                cost += quad(Qsym, e, NR) + quad(Rsym, dv, M);
-            }
-            irs_step_along<Model>(a.p, xr, ur, xn, &warm);
+            for (int i = 0; i < NR; ++i) xs[i] = xr[i];
+            irs_step_along_finish<Model>(a.p, xr, ur, pre, xn, &warm);
 #pragma unroll
             for (int i = 0; i < NR; ++i) xr[i] = xn[i];
 #pragma unroll
             for (int j = 0; j < M; ++j) up[j] = ur[j];
-            if (lane == 0) {
-#pragma unroll
-                for (int j = 0; j < M; ++j) a.u_new[(size_t)tau * M + j] = ur[j];
-#pragma unroll
-                for (int i = 0; i < NR; ++i) a.x_new[(size_t)(tau + 1) * NR + i] = xr[i];
-            }
             publish_start();
         }
+        book(T - 1);
         {
             double e[NR];
 #pragma unroll
