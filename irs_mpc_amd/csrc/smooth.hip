@@ -678,7 +678,21 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
         // flight), then evaluated; out-of-range slots are clamped to a valid address and
         // zeroed (a zero perturbation contributes exactly nothing to the zero-order sums).
         constexpr int U = (TR::LIGHT && !RNG) ? 4 : 1;
-        for (int s0 = s_begin + tid; s0 < s_end; s0 += BLOCK * U) {
+        // kernels whose workgroup 0 evaluates the f64 nominal step deal 64-sample blocks to WAVES (block_of, as in
+        // the parked-sample loop above): trip k of wave w takes block NW k + w; in workgroup 0 the last wave sits out
+        // after a.wg0_rr trips.  Everything else: the plain strided loop.
+        const int rr_ = (NB && blk == 0) ? a.wg0_rr : 0x7fffffff;
+        auto next_s0 = [&](int k) {
+            if constexpr (NB) {
+                if (k < rr_) return s_begin + tid + k * BLOCK;
+                if ((tid >> 6) == NW - 1) return s_end;
+                return s_begin + 64 * (NW * rr_ + (NW - 1) * (k - rr_)) + tid;
+            } else {
+                return s_begin + tid + k * BLOCK;
+            }
+        };
+        int kt_ = 0;
+        for (int s0 = s_begin + tid; s0 < s_end; s0 = (NB && U == 1) ? next_s0(++kt_) : s0 + BLOCK * U) {
             float zz[U][d];
             bool valid[U];
 #pragma unroll
@@ -757,8 +771,8 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
     }
     if constexpr (NB) {
         // (a lone fused workgroup lets its solve evaluate the step itself: same cost, no round trip)
-        constexpr int NOMW = DEFER ? NW - 1 : 0;           // the wave that evaluates it (parked-sample kernels: the one
-                                                           // that was dealt fewer sample trips)
+        constexpr int NOMW = NW - 1;                        // the wave that evaluates it: the one that is dealt fewer
+                                                           // sample trips (a.wg0_rr)
         if (blk == 0 && (a.nblk > 1 || !FUSE) && (tid >> 6) == NOMW) {
             double x64[n], u64[m], f64[n];
 #pragma unroll
@@ -1010,6 +1024,10 @@ bool has_nominal_in_wg0(int model, int /*mode*/) {
     return r;
 }
 
+// what the f64 nominal step costs the wave of workgroup 0 that evaluates it, in 64-sample trips of the same kernel
+// (measured per kernel family; IRS_NOMINAL_TRIPS overrides for tuning)
+int nominal_trips(int model, int mode);
+
 // smooth_kernel's DEFER path (defer_samples<Model, MODE>)
 bool uses_parked_samples(int model, int mode) {
     bool r = false;
@@ -1018,6 +1036,14 @@ bool uses_parked_samples(int model, int mode) {
                                            : mode == IRS_SMOOTH_ZERO_ORDER_B ? defer_samples<Model, IRS_SMOOTH_ZERO_ORDER_B>() : false;
     });
     return r;
+}
+
+int nominal_trips(int model, int mode) {
+    static int ov = env_int("IRS_NOMINAL_TRIPS", -1);
+    if (ov >= 0) return ov;
+    (void)model; (void)mode;
+    return kNominalTrips;      // measured: 1-3 trips are equal for every contact kernel (planar hand exact / sweeps /
+                               // first-order, box pivoting); 4 and more lose a trip
 }
 
 template <class Model>
@@ -1103,15 +1129,16 @@ int smooth_common(int model, const double* params, int n_params, int mode, int T
     a.chunk0 = a.chunk;
     a.wg0_rr = 0x7fffffff;
     bool planned = false;
-    if (a.nblk >= 2 && a.block == kBlock && uses_parked_samples(model, mode)) {
-        // parked-sample kernels balance by WAVE trips (64 samples): B blocks plus the nominal step's kNominalTrips
+    if (a.nblk >= 2 && a.block == kBlock && has_nominal_in_wg0(model, mode)) {
+        // contact kernels balance by WAVE trips (64 samples): B blocks plus the nominal step's kNominalTrips
         // over 4 nblk waves -> tt trips each; workgroup 0: tt - kNominalTrips rounds over its four waves, then
         // kNominalTrips rounds over three.  (Chunks rounded to whole workgroup trips, as below, left three of the
         // five workgroups of the benchmark's N = 1e4 with 9 trips and one with 5 + the nominal step.)
         const int NW = kBlock / 64, B = (N + 63) / 64, nw = a.nblk * NW;
-        const int tt = (B + kNominalTrips + nw - 1) / nw, rr = tt - kNominalTrips;
+        const int kNom = nominal_trips(model, mode);
+        const int tt = (B + kNom + nw - 1) / nw, rr = tt - kNom;
         if (rr >= 1) {
-            const int c0b = NW * rr + (NW - 1) * kNominalTrips;
+            const int c0b = NW * rr + (NW - 1) * kNom;
             const int restb = B > c0b ? (B - c0b + (a.nblk - 1) - 1) / (a.nblk - 1) : 0;
             if (restb <= NW * tt) {
                 a.chunk0 = c0b * 64;
