@@ -472,6 +472,8 @@ def main():
         for _ in range(steps):
             fn()
         ev1.record()
+        while not ev1.query():          # spin until the last step has retired: a blocking synchronize() alone wakes the
+            pass                        # host ~100 us late, which a 20-step region (the driver's default) would carry
         torch.cuda.synchronize()
         barrier()
         el = time.perf_counter() - t0
