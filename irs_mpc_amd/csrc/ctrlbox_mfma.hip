@@ -43,6 +43,10 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) double* gptr_d;
 
 constexpr int kPdasIterM = 10;
+#ifndef IRS_LAZY_MIN
+#define IRS_LAZY_MIN 6
+#endif
+constexpr int kLazyPrefixMin = IRS_LAZY_MIN;   // shortest fully pinned head that is left out of the inner sweeps
 constexpr int KIND_ABS_M = 0, KIND_REL_M = 1;
 
 // 1/d: hardware estimate + two Newton steps (~1 ulp).  (The policy-evaluation form would forgive a cruder
@@ -90,7 +94,8 @@ struct MfLayout {
     static __host__ __device__ size_t oP(int T) { return (size_t)T * GT; }
     static __host__ __device__ size_t oV(int T) { return oP(T) + (size_t)(T + 1) * PT; }       // 7 x (T, M)
     static __host__ __device__ size_t oQ(int T) { return oV(T) + (size_t)7 * T * M; }          // (T+1, NR)
-    static __host__ __device__ size_t rec_doubles(int T) { return oQ(T) + (size_t)(T + 1) * NR; }
+    static __host__ __device__ size_t oS(int T) { return oQ(T) + (size_t)(T + 1) * NR; }       // (T) tile signatures
+    static __host__ __device__ size_t rec_doubles(int T) { return oS(T) + (size_t)T; }
     // always in LDS: Qsym, Qdsym (NR^2), Rsym (M^2), sstart (NH), uctl (M), slack, and 128 doubles the lanes that
     // have nothing to write aim their stores at (forward sweep: unconditional stores, no exec-mask branch)
     static constexpr int small = 2 * NR * NR + M * M + NH + M + 16 + 128;
@@ -145,6 +150,7 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
     double* mu_ = Vv + (size_t)5 * T * M;
     double* bnd_ = Vv + (size_t)6 * T * M;                 // the bound a pinned component sits at (follows act_)
     double* qsd = rec + L::oQ(T);
+    double* sig_ = rec + L::oS(T);                          // 1: step t is fully pinned and its tile was computed for this set
     double* Qsym = sm;
     double* Qdsym = Qsym + NR * NR;
     double* Rsym = Qdsym + NR * NR;
@@ -299,6 +305,7 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
         qsd[q] = -s;                                        // -(Qs sd_t)[:NR] (the tile's linear entries); the w block of sd is zero
     }
     for (size_t q = lane; q < (size_t)T * L::GT; q += 64) Gt[q] = 0.0;      // unwritten image entries stay zero
+    for (int q = lane; q < T; q += 64) sig_[q] = -1.0;                        // no tile yet
     // stage-cost tile without its time-varying column, in C/D layout (row = rg + 4 r, col)
     auto Ru = [&](int i, int j) { return Rsym[i * M + j]; };
     v4d Lc;
@@ -462,6 +469,14 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
 #pragma unroll
                 for (int i = 0; i < M; ++i)
                     if (i == rg) Kb = col == NS ? bb[i] : 0.0;
+                // this tile's closed loop holds for as long as the step's active set does (lazy prefix, below):
+                // sig_ = 1 here, reset to -1 wherever act_ changes
+                if constexpr (LDSREC) {
+                    double* sp = lane == 0 ? sig_ + t : junk + lane;
+                    *sp = 1.0;
+                } else if (lane == 0) {
+                    sig_[t] = 1.0;
+                }
                 CBM_MARK(9);
             } else {
                 double H[M][M], gc[M], mf[M], bz[M];
@@ -621,7 +636,7 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
     };
 
     // ---- policy rollout on the linear model from sstart: controls -> `dst` (uu_ or us_), multipliers -> mu_ ----
-    auto policy_rollout = [&](int t0, double* dst) {
+    auto policy_rollout = [&](int t0, double* dst, int te) {          // steps t0 .. te-1
         CBM_T0();
         v4d S = {0.0, 0.0, 0.0, 0.0};
         if (col == 0) {
@@ -675,14 +690,14 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
 #ifdef IRS_CBM_STAMPS
         const long long st_fl0 = __builtin_amdgcn_s_memtime();
 #endif
-        for (; t + 1 < T; t += 2) {
+        for (; t + 1 < te; t += 2) {
             fetch(fb);
             step(fa, S, S1, hp);
-            if (t + 2 < T) fetch(fa);
+            if (t + 2 < te) fetch(fa);
             step(fb, S1, S, true);
             hp = true;
         }
-        if (t < T) {
+        if (t < te) {
             step(fa, S, S1, hp);
             emit(S1);
         } else if (hp) {
@@ -695,14 +710,14 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
 #endif
         rsync();
         // controls and multipliers from the raw rows
-        for (int q = t0 * M + lane; q < T * M; q += 64) {
+        for (int q = t0 * M + lane; q < te * M; q += 64) {
             const double raw = mu_[q], ac = act_[q];
             const double bd = bnd_[q];
             dst[q] = ac == 0.0 ? raw : bd;
             mu_[q] = ac == 0.0 ? 0.0 : raw;
         }
         rsync();
-        CBM_ADD(2, T - t0);
+        CBM_ADD(2, te - t0);
     };
 
     // ---- cold start of the first tail: the SATURATED unconstrained policy.  With every component free the
@@ -740,6 +755,7 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
                 if (lane == 0) {
                     act_[(size_t)t * M + j] = v < lo - tol_ ? -1.0 : (v > hi + tol_ ? 1.0 : 0.0);
                     bnd_[(size_t)t * M + j] = v < lo - tol_ ? lo : hi;
+                    sig_[t] = -1.0;
                 }
             }
             // s~+ rows (column 0): x rows += B delta, w rows += delta
@@ -790,30 +806,83 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
         int t_dirty = full ? T - 1 : t0 - 1;           // the sweep of the previous tail covers t >= tau
         int iters = 0;
         bool conv = false;
-        // ---- phase 1: primal-dual active set
+        // ---- phase 1: primal-dual active set, with a LAZY PREFIX.  A fully pinned step's closed loop is
+        // A~ + B~ b e_h' whatever the cost-to-go: the rollout through it does not depend on the sweep; only its
+        // multiplier rows Y_t do.  The saturated head of a trust-region tail -- the contiguous run of fully pinned
+        // steps from t0 whose tiles were computed for the current set (sig_) -- is therefore left out of the inner
+        // iterations' sweeps (its multipliers are not consulted meanwhile) and swept ONCE, when the rest has
+        // settled: then its multipliers are tested, and a wrong-signed one re-opens the iteration.  The solution of
+        // the strictly convex QP does not depend on the order in which violated conditions are repaired; every
+        // condition is verified on fresh records before the tail is accepted.  (Trust-region benchmark: 73 % of the
+        // backward steps were re-sweeps of that head.)
+        int stale_hi = t0 - 1;                         // records of [t0, stale_hi] are out of date (skipped prefix)
+        auto prefix_end = [&]() {                      // last step of the run described above (t0 - 1: none)
+            int pe = t0 - 1;
+            for (int base = t0; base < T; base += 64) {
+                const int t = base + lane;
+                bool ok = false;
+                if (t < T) {
+                    bool allp = sig_[t] == 1.0;
+#pragma unroll
+                    for (int j = 0; j < M; ++j) allp = allp && act_[(size_t)t * M + j] != 0.0;
+                    ok = allp;
+                }
+                const unsigned long long bal = __ballot(ok);
+                const int run = bal == ~0ull ? 64 : __builtin_ctzll(~bal);
+                pe = base + run - 1;
+                if (run < 64) break;
+            }
+            return pe;
+        };
         for (int it = 0; it < kPdasIterM && !conv; ++it) {
             ++iters;
-            backward_sweep(t_dirty, t0);
-            policy_rollout(t0, uu_);
+            // (a short run is not worth an extra rollout and a later release: measured on the rate-limited box
+            // problem, where skipping 1-3 steps cost more iterations than it saved sweeps)
+            int pe = t0 - 1;
+            if (max(t_dirty, stale_hi) >= t0) {        // (nothing to sweep: no need to know)
+                pe = prefix_end();
+                if (pe - t0 + 1 < kLazyPrefixMin) pe = t0 - 1;
+            }
+            {
+                const int hi = max(t_dirty, stale_hi), lo = max(t0, pe + 1);
+                if (hi >= lo) backward_sweep(hi, lo);
+                if (hi >= t0) stale_hi = lo - 1;       // what was dirty below lo stays so
+            }
+            policy_rollout(t0, uu_, T);
             int chg = -1;
             for (int q = t0 * M + lane; q < T * M; q += 64) {
                 const double ac = act_[q], u = uu_[q], mu = mu_[q];
+                const bool fresh = q / M > stale_hi;   // multipliers of the skipped prefix are not current
                 double nw = ac;
                 if (ac == 0.0) {
                     if (u < lo_[q] - tol) nw = -1.0;
                     else if (u > hi_[q] + tol) nw = 1.0;
                 } else if (ac < 0.0) {
-                    if (mu < -tol) nw = 0.0;
+                    if (fresh && mu < -tol) nw = 0.0;
                 } else {
-                    if (mu > tol) nw = 0.0;
+                    if (fresh && mu > tol) nw = 0.0;
                 }
-                if (nw != ac) { act_[q] = nw; bnd_[q] = nw < 0.0 ? lo_[q] : hi_[q]; chg = max(chg, q / M); }
+                if (nw != ac) { act_[q] = nw; bnd_[q] = nw < 0.0 ? lo_[q] : hi_[q]; sig_[q / M] = -1.0; chg = max(chg, q / M); }
             }
             chg = wmax_i(chg);
             rsync();
+            if (chg < 0 && stale_hi >= t0) {
+                // the rest has settled: sweep the skipped prefix once and test ITS multipliers
+                const int ph = stale_hi;
+                backward_sweep(ph, t0);
+                stale_hi = t0 - 1;
+                policy_rollout(t0, uu_, ph + 1);
+                for (int q = t0 * M + lane; q < (ph + 1) * M; q += 64) {
+                    const double ac = act_[q], mu = mu_[q];
+                    if ((ac < 0.0 && mu < -tol) || (ac > 0.0 && mu > tol)) { act_[q] = 0.0; sig_[q / M] = -1.0; chg = max(chg, q / M); }
+                }
+                chg = wmax_i(chg);
+                rsync();
+            }
             if (chg < 0) conv = true;
             else t_dirty = chg;
         }
+        if (stale_hi >= t0) { t_dirty = max(t_dirty, stale_hi); stale_hi = t0 - 1; }      // phase 2 sweeps everything dirty
         // ---- phase 2: primal active set from the clipped iterate
         if (!conv) {
             int chg = -1;
@@ -822,7 +891,7 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
                 const double u = fmin(fmax(uu_[q], lo), hi);
                 uu_[q] = u;
                 const double nw = u <= lo ? -1.0 : (u >= hi ? 1.0 : 0.0);
-                if (nw != act_[q]) { act_[q] = nw; bnd_[q] = nw < 0.0 ? lo : hi; chg = max(chg, q / M); }
+                if (nw != act_[q]) { act_[q] = nw; bnd_[q] = nw < 0.0 ? lo : hi; sig_[q / M] = -1.0; chg = max(chg, q / M); }
             }
             chg = wmax_i(chg);
             rsync();
@@ -831,7 +900,7 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
                 ++iters;
                 backward_sweep(t_dirty, t0);
                 t_dirty = t0 - 1;
-                policy_rollout(t0, us_);
+                policy_rollout(t0, us_, T);
                 // largest feasible step along d = us - u over the free components
                 double best = INF;
                 int bq = 0x7fffffff;
@@ -853,6 +922,7 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
                             act_[q] = d > 0.0 ? 1.0 : -1.0;
                             uu_[q] = d > 0.0 ? hi_[q] : lo_[q];
                             bnd_[q] = uu_[q];
+                            sig_[q / M] = -1.0;
                         } else {
                             uu_[q] = u + alpha * d;
                         }
@@ -876,7 +946,7 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
                     conv = true;
                 } else {
                     const int qw = wmin_i(worst == wmax ? wq : 0x7fffffff);
-                    if (lane == 0) act_[qw] = 0.0;
+                    if (lane == 0) { act_[qw] = 0.0; sig_[qw / M] = -1.0; }
                     rsync();
                     t_dirty = qw / M;
                 }
