@@ -822,6 +822,12 @@ def main():
             out["cpu_baseline"] = cpu_base
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
+    if os.environ.get("IRS_PRINT_STAMPS"):      # diagnostic library only (tools/stamp_descent.sh): phases of the LAST descent
+        from irs_mpc_amd import _lib
+        lib = _lib.load()
+        if hasattr(lib, "irs_cbm_print_stamps"):
+            lib.irs_cbm_print_stamps.restype = None
+            lib.irs_cbm_print_stamps()
     if world > 1 or args.force_unfused:
         dist.destroy_process_group()
 

@@ -62,6 +62,14 @@ __device__ __forceinline__ double readlane_d(double v, int src) {
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
     return __hiloint2double(hi, lo);
 }
+// lane N of every 16-lane row to all lanes of that row (DPP row_newbcast; checked on gfx950: tools/microbench)
+template <int N>
+__device__ __forceinline__ double row_newbcast_d(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + N, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + N, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wmax_d(double v) {
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) v = fmax(v, __shfl_xor(v, s, 64));
@@ -480,16 +488,29 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
                 CBM_MARK(9);
             } else {
                 double H[M][M], gc[M], mf[M], bz[M];
-                // (staging these through an LDS tile instead -- 1 write, 16 broadcast + 4 strided reads -- was
-                // measured equal: the phase is bound by the count of f64 instructions, ~8 cycles each for a lone wave)
-    #pragma unroll
+                // One product with a constant selector replicates the rows of Theta_nu over the lane groups:
+                //   Gc[r] (every lane) = Theta_nu[r][col]      (A[row][k] = [k == row >> 2], B = register RN as it is)
+                // -- that is gc -- and H[i][j] = Theta_nu[i][NHP + j] is lane NHP + j of each 16-lane row of Gc[i]:
+                // a DPP row broadcast.  (20 v_readlane into SGPRs + 8 ds_bpermute behind the last product of Theta
+                // took ~1000 cycles per free step; staging through an LDS tile was no faster.)
+                const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
+                const v4d Gc = __builtin_amdgcn_mfma_f64_16x16x4f64(rg == (col >> 2) ? 1.0 : 0.0, Th[RN], zero4, 0, 0, 0);
+                auto bc = [&](double v, int j) {
+                    switch (j) {
+                        case 0: return row_newbcast_d<NHP + 0>(v);
+                        case 1: return row_newbcast_d<(NHP + 1) & 15>(v);
+                        case 2: return row_newbcast_d<(NHP + 2) & 15>(v);
+                        default: return row_newbcast_d<(NHP + 3) & 15>(v);
+                    }
+                };
+#pragma unroll
                 for (int i = 0; i < M; ++i) {
-    #pragma unroll
+#pragma unroll
                     for (int j = i; j < M; ++j) {
-                        H[i][j] = readlane_d(Th[RN], 16 * i + NHP + j);
+                        H[i][j] = bc(Gc[i], j);
                         H[j][i] = H[i][j];
                     }
-                    gc[i] = __shfl(Th[RN], 16 * i + col, 64);
+                    gc[i] = Gc[i];
                     mf[i] = ac[i] == 0.0 ? 1.0 : 0.0;
                     bz[i] = ac[i] == 0.0 ? 0.0 : bb[i];          // pinned value, 0 for a free component
                 }

@@ -11,3 +11,5 @@ cd $R/irs_mpc_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/gpurun_out/libirs_hip_stamps.so plugin.o smooth.o tvlqr.o cem.o boxqp.o ctrlbox.o collective.o /tmp/ctrlbox_mfma_stamps.o -ldl
 cd $R
 IRS_HIP_LIB=$R/gpurun_out/libirs_hip_stamps.so python tools/time_quasistatic.py "$@" --stamps
+# ... and the LAST descent of the benchmark's iLQR loop (a warm-started one, late in an episode)
+IRS_PRINT_STAMPS=1 IRS_HIP_LIB=$R/gpurun_out/libirs_hip_stamps.so python bench.py --no-cpu-baseline --no-secondary --steps 200 --warmup 20 > /dev/null
