@@ -491,8 +491,10 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
                 // One product with a constant selector replicates the rows of Theta_nu over the lane groups:
                 //   Gc[r] (every lane) = Theta_nu[r][col]      (A[row][k] = [k == row >> 2], B = register RN as it is)
                 // -- that is gc -- and H[i][j] = Theta_nu[i][NHP + j] is lane NHP + j of each 16-lane row of Gc[i]:
-                // a DPP row broadcast.  (20 v_readlane into SGPRs + 8 ds_bpermute behind the last product of Theta
-                // took ~1000 cycles per free step; staging through an LDS tile was no faster.)
+                // a DPP row broadcast.  (Instead of 20 v_readlane into SGPRs + 8 ds_bpermute; staging through an LDS
+                // tile was tried too.  Measured with the in-kernel stamps: whichever way H travels, gather + inverse
+                // of a free step take ~1100 cycles together -- the wait for Theta's last product and then ~110 f64
+                // operations of one wave at ~8 cycles each; this form keeps the SGPRs free and is 1 % faster.)
                 const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
                 const v4d Gc = __builtin_amdgcn_mfma_f64_16x16x4f64(rg == (col >> 2) ? 1.0 : 0.0, Th[RN], zero4, 0, 0, 0);
                 auto bc = [&](double v, int j) {
