@@ -527,7 +527,19 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
     #pragma unroll
                 for (int i = 0; i < M; ++i)
     #pragma unroll
-                    for (int j = 0; j < M; ++j) Hm[i][j] = i == j ? (ac[i] == 0.0 ? H[i][i] : 1.0) : H[i][j] * (mf[i] * mf[j]);
+                    for (int j = 0; j < M; ++j) Hm[i][j] = H[i][j];
+                // a step with NO pinned component (most steps of a converging iLQR run) needs no masking and no
+                // pinned-value terms: ~35 of the phase's ~110 f64 operations, behind a wave-uniform branch
+                bool anypin = false;
+    #pragma unroll
+                for (int j = 0; j < M; ++j) anypin = anypin || ac[j] != 0.0;
+                const bool pins = __builtin_amdgcn_readfirstlane((int)anypin) != 0;
+                if (pins) {
+    #pragma unroll
+                    for (int i = 0; i < M; ++i)
+    #pragma unroll
+                        for (int j = 0; j < M; ++j) Hm[i][j] = i == j ? (ac[i] == 0.0 ? H[i][i] : 1.0) : H[i][j] * (mf[i] * mf[j]);
+                }
                 bool spd = true;
                 auto inv2 = [&](double p, double q, double r, double& ip, double& iq, double& ir) {
                     // [p q; q r]^-1 = [r -q; -q p] / (p r - q^2)
@@ -571,13 +583,19 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
     #pragma unroll
                 for (int i = 0; i < M; ++i) {
                     // right-hand side of the free rows: Theta_f,col + (homogeneous column) sum_p H_fp b_p
-                    double hb0 = 0.0, hb1 = 0.0;
+                    rhs[i] = gc[i];
+                }
+                if (pins) {
     #pragma unroll
-                    for (int l = 0; l < M; ++l) {
-                        if (l & 1) hb1 = fma(H[i][l], bz[l], hb1);
-                        else hb0 = fma(H[i][l], bz[l], hb0);
+                    for (int i = 0; i < M; ++i) {
+                        double hb0 = 0.0, hb1 = 0.0;
+    #pragma unroll
+                        for (int l = 0; l < M; ++l) {
+                            if (l & 1) hb1 = fma(H[i][l], bz[l], hb1);
+                            else hb0 = fma(H[i][l], bz[l], hb0);
+                        }
+                        rhs[i] = fma(hsel, hb0 + hb1, gc[i]) * mf[i];
                     }
-                    rhs[i] = fma(hsel, hb0 + hb1, gc[i]) * mf[i];
                 }
     #pragma unroll
                 for (int i = 0; i < M; ++i) {
