@@ -696,7 +696,7 @@ def main():
         assert info == 0, "smoothing solve reported a non-SPD Gram matrix or a non-finite statistic"
         return el, el_it, k_ms, (n, m), loop
 
-    def sub_report(w_, N_, steps_, warm_=None, **kw):
+    def sub_report(w_, N_, steps_, warm_=None, sweep_N=(), **kw):
         e, ei, km, nm_, lp = run(w_, N_, steps_, warm_ if warm_ is not None else max(1, steps_ // 10), **kw)
         r = {"config": {"workload": w_.label, "T": w_.T, "N_per_gpu": N_, "mode": w_.mode_name},
              "value": N_ * w_.T * steps_ / e, "unit": "rollouts*timesteps/s", "steps": steps_,
@@ -705,6 +705,14 @@ def main():
              "ilqr_first_iter_per_s": steps_ / ei, "roofline": roofline(w_, N_, km, nm_)}
         if lp:
             r["ilqr_loop"] = lp
+        if sweep_N:                                   # north_star's other N points for this workload
+            r["sweep_N"] = {}
+            for Ns in sweep_N:
+                st = max(20, steps_ // (4 if Ns <= 10000 else 16))
+                e2, ei2, km2, nm2, _ = run(w_, Ns, st, max(2, st // 10), **kw)
+                r["sweep_N"][str(Ns)] = {"value": Ns * w_.T * st / e2, "ms_per_step": 1e3 * e2 / st, "avg_launch_ms": km2,
+                                         "ilqr_iters_per_s": st / ei2,
+                                         "hbm_GBps": w_.bytes_per_sample(*nm2) * Ns * w_.T / (km2 * 1e-3) / 1e9}
         return r
 
     def run_cem(w, B, iters, n_ep=2):
@@ -797,9 +805,9 @@ def main():
         out["pgs_contact_solver"] = sub_report(Workload("planar_hand", args.T, None, contact_solver="pgs"), N,
                                                max(20, args.steps // 4))
     if secondary and w.name != "pendulum":
-        out["pendulum"] = sub_report(Workload("pendulum"), 10000, max(200, 5 * args.steps), 1000)
+        out["pendulum"] = sub_report(Workload("pendulum"), 10000, max(200, 5 * args.steps), 1000, sweep_N=(1000, 100000))
     if secondary and w.name != "quadrotor":
-        out["quadrotor"] = sub_report(Workload("quadrotor"), 10000, max(100, args.steps))
+        out["quadrotor"] = sub_report(Workload("quadrotor"), 10000, max(100, args.steps), sweep_N=(1000, 100000))
     if secondary and w.name != "box_pivoting":
         # BASELINE configs[4]: T = 80, N = 5e4 over 8 GPUs -> 6250 samples per timestep per GPU
         wb = Workload("box_pivoting")
