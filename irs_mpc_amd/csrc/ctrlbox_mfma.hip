@@ -880,7 +880,10 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
             // (a short run is not worth an extra rollout and a later release: measured on the rate-limited box
             // problem, where skipping 1-3 steps cost more iterations than it saved sweeps)
             int pe = t0 - 1;
-            if (max(t_dirty, stale_hi) >= t0) {        // (nothing to sweep: no need to know)
+            // Trust-region (ABS) problems only: their tails start with a long saturated head.  Rate-limited (REL)
+            // ones rarely do, and deferring the few releases there costs iterations (measured on the benchmark's
+            // box-pivoting loop: 206 -> 187 iterations/s with it, planar hand trust region 579 -> 596).
+            if (KIND == KIND_ABS_M && max(t_dirty, stale_hi) >= t0) {   // (nothing to sweep: no need to know)
                 pe = prefix_end();
                 if (pe - t0 + 1 < kLazyPrefixMin) pe = t0 - 1;
             }
