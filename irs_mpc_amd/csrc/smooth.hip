@@ -477,7 +477,7 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
                     philox_normal4(gidx, (unsigned)t, (unsigned)j, a.iter, a.seed, g);
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        if (4 * j + c < d) z[4 * j + c] = g[c] * a.std[4 * j + c];
+                        if (4 * j + c < d) z[4 * j + c] = __fmul_rn(g[c], a.std[4 * j + c]);   // rounded like a supplied f32 sample (no fma with the nominal point)
                 }
             } else {
                 const size_t row = (size_t)t * a.N + (valid ? s : s_end - 1);
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
                         philox_normal4(gidx, (unsigned)t, (unsigned)j, a.iter, a.seed, g);
 #pragma unroll
                         for (int c = 0; c < 4; ++c)
-                            if (4 * j + c < d) z[4 * j + c] = g[c] * a.std[4 * j + c];
+                            if (4 * j + c < d) z[4 * j + c] = __fmul_rn(g[c], a.std[4 * j + c]);   // rounded like a supplied f32 sample (no fma with the nominal point)
                     }
 #pragma unroll
                     for (int i = 0; i < Z0; ++i) z[i] = 0.f;
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
                         philox_normal4(gidx, (unsigned)t, (unsigned)j, a.iter, a.seed, g);
 #pragma unroll
                         for (int c = 0; c < 4; ++c)
-                            if (4 * j + c < d) zz[uu][4 * j + c] = g[c] * a.std[4 * j + c];
+                            if (4 * j + c < d) zz[uu][4 * j + c] = __fmul_rn(g[c], a.std[4 * j + c]);   // rounded like a supplied f32 sample (no fma with the nominal point)
                     }
 #pragma unroll
                     for (int i = 0; i < Z0; ++i) zz[uu][i] = 0.f;

@@ -975,6 +975,43 @@ def test_parked_samples_are_finished_exactly_once(amd, N):
     np.testing.assert_allclose(o2["Bt"].cpu().numpy()[0][free], B2[free], rtol=0, atol=5e-6)
 
 
+@pytest.mark.parametrize("system", ["planar_hand", "box_pivoting"])
+def test_contact_sample_pass_device_rng_equals_supplied_samples(amd, system):
+    """Mode G of the contact kernels (perturbations drawn inside the launch, Philox keyed by the GLOBAL sample index)
+    against the same kernels fed the same draws from the host (oracle.device_gaussian_samples restates the
+    generator): the RNG instantiations, the block-to-wave dealing and the parked-sample ring must not change which
+    sample is which.  What the iLQR loop of bench.py runs.  Zero-order-B is continuous in the sample: equal to
+    rounding.  First-order is piecewise constant in the sample, and the planar hand's grasp is statically
+    indeterminate (8 contact rows on 7 dofs: the multipliers of the step QP are not unique, only its primal solution
+    is): which rows end up carrying the load is decided at rounding level, two instantiations of the same f32 code
+    (different fma contraction) decide it differently for ~0.4 % of the samples, and the derivative THROUGH the
+    active set differs between such sets.  Measured: 3.7e-3 on B at N = 5000 -- the Monte-Carlo error of the
+    estimate itself is ~3e-3.  Box pivoting has no such freedom at this state and agrees to a few samples."""
+    from irs_mpc_amd import device as dev
+    from irs_mpc_amd._lib import SMOOTH_FIRST_ORDER, SMOOTH_ZERO_ORDER_B
+    T, N, seed, it = 3, 5000, 11, 2
+    if system == "planar_hand":
+        sys_d, sys_o = amd.PlanarHandDynamics(0.1), orc.PlanarHandOracle(0.1)
+        x0 = HAND.pack([0.0, 0.35, 0.0], [-np.pi / 4, -np.pi / 4], [np.pi / 4, np.pi / 4])
+        x0 = orc.rollout(sys_o, x0, np.tile(x0[HAND_IDX], (25, 1)))[-1]          # the settled grasp
+    else:
+        sys_d, sys_o = amd.BoxPivotingDynamics(0.1), orc.BoxPivotOracle(0.1)
+        x0 = orc.BoxPivotOracle.pack([0.0, 0.5, 0.0], [-0.6, 0.3])
+    idx = sys_o.indices_u_into_x
+    n, m = sys_o.dim_x, sys_o.dim_u
+    u_trj = np.tile(x0[idx], (T, 1))
+    x_trj = orc.rollout(sys_o, x0, u_trj)
+    xd, ud = dev.to_dev(x_trj), dev.to_dev(u_trj)
+    su = np.full(m, 0.1)
+    _, du = orc.device_gaussian_samples(T, N, n, m, np.zeros(n), su, seed, it, dtype=np.float32)
+    dm = sys_d.dm()
+    for mode, tol in ((SMOOTH_ZERO_ORDER_B, 2e-6), (SMOOTH_FIRST_ORDER, 2e-2 if system == "planar_hand" else 5.0 / N)):
+        a = dm.smooth_rng(mode, xd, ud, N, None, su, seed, it)
+        b = dm.smooth(mode, xd, ud, None, dev.to_dev(du, dev.F32))
+        for k in ("At", "Bt", "ct"):
+            np.testing.assert_allclose(a[k].cpu().numpy(), b[k].cpu().numpy(), rtol=0, atol=tol, err_msg="%s mode %d" % (k, mode))
+
+
 def test_planar_hand_exact_contact_solver_vs_oracle(amd):
     """contact_solver="exact" (IRS_MODEL_PLANAR_HAND_EXACT): the device's dual active-set solve of the step QP
     == the oracle's (`pgs_iters = 0`) in f64 (dynamics, active-set Jacobian), and through the f32 sample
