@@ -300,7 +300,8 @@ size_t irs_tvlqr_box_lds_bytes(int model, int T);
  *   tail, rho/relax unused; one wave, every quantity of all T steps in LDS (planar hand: T <= 52);
  *   3 = the same method with every step riding in one 16 x 16 matrix-core tile of homogeneous
  *   coordinates (csrc/ctrlbox_mfma.hip; models with n + 2 m + 1 <= 16 after padding: all contact
- *   models here): ~7x faster, and no horizon limit -- per-step records stay in LDS when they fit and
+ *   models here): ~5x faster, and no horizon limit -- per-step records stay in LDS when they fit (planar
+ *   hand T <= 53, box pivoting T <= 123) and
  *   otherwise live in the workspace of irs_quasistatic_box_descent_wsx;
  *   0 = 3 where it applies (on chip, or a workspace was given), else 2 where it fits LDS, else 1.
  * cost (1) DEV (may be NULL); info (3): [0] t+1 of a non-PD Hessian, [1] most iterations any tail
