@@ -565,23 +565,27 @@ IRS_HD bool irs_contact_qp_dual_exact_try(const T* Dinv, const T* b, const T (*J
         for (int i = j + 1; i < NC; ++i) v = v - M_[j][i] * y[i];
         y[j] = v;
     }
-    bool good = true;
+    // the tests as min-reductions (one compare each at the end): a chain of `good && ...` over 2 NC vector compares
+    // serialises on the scalar unit -- measured 1 590 cycles for ~110 instructions
     unsigned mk = 0u;
+    T ymin = T(3.0e38);
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         const bool neg = act[i] && !(y[i] > T(0));
-        good = good && !neg;
+        ymin = fmin(ymin, act[i] ? y[i] : T(3.0e38));
         lam[i] = act[i] ? y[i] : T(0);
         mk |= (act[i] && !neg) ? (1u << i) : 0u;
     }
     // slacks off the set: all >= -tol <=> optimal
+    T smin = T(3.0e38);
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         T s = r[i];
 #pragma unroll
         for (int j = 0; j < NC; ++j) s = s + W[i][j] * lam[j];
-        good = good && (act[i] || s >= -tolv);
+        smin = fmin(smin, act[i] ? T(3.0e38) : s);
     }
+    const bool good = ymin > T(0) && smin >= -tolv;
     *mask = mk;
     return good;
 }

@@ -421,7 +421,10 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
     // 39 % of their samples are unfinished after the first attempt, and W (144) + its factor live across the loop
     // spill 200 VGPRs: 123 -> 225 us.
     constexpr bool DEFER = defer_samples<Model, MODE>();
-    constexpr int QE = NZ + 1;
+    // perturbed components of a sample in the u-only modes (NOT TR::NZ: that is the width of the least-squares design,
+    // d for the first-order statistics) + the warm set
+    constexpr int NPERT = d - Z0;
+    constexpr int QE = NPERT + 1;
     __shared__ float defer_ring[DEFER ? NW * kDeferRing * QE : 1];
     __shared__ float red[NW * TR::PP];
     __shared__ float tile[USE_MFMA ? NW * 64 * 36 : 1];
@@ -528,7 +531,7 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
         // ---- exact contact models: finished samples accumulate at once, unfinished ones are parked ----------
         // irs_contact_step_try (contact_models.hpp) settles ~90 % of the samples with straight-line code; the
         // rest -- those whose guessed active set needs repair rounds or active-set steps, loops that run as long
-        // as a wave's slowest lane -- are parked in this wave's LDS ring (the perturbation + the warm set, NZ + 1
+        // as a wave's slowest lane -- are parked in this wave's LDS ring (the perturbation + the warm set, m + 1
         // dwords) and finished 64 at a time with every lane busy: as soon as 64 are waiting, and once more after
         // the wave's last sample.  Everything is wave-private and in lane order (ballot prefix, wave-uniform
         // head/tail): no barrier, no atomic, and the same sample lands in the same lane's accumulator in every
@@ -578,6 +581,18 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
             return wave == NW - 1 ? 0x3fffffff : NW * rr + (NW - 1) * (k - rr) + wave;
         };
         int sb = s_begin + 64 * block_of(0);
+        // supplied samples: the perturbation of the NEXT fresh trip is loaded while this one computes -- a lone wave
+        // per SIMD has nothing else to cover the ~2000 cycles of a dependent global load at the head of every trip
+        // (measured with in-kernel stamps: 4 050 of a trip's 15 500 cycles were load + primal + accumulate)
+        float zpre[NPERT];
+        auto prefetch = [&](int sbn) {
+            if constexpr (!RNG) {
+                const int sn = sbn + lane;
+                const size_t row = (size_t)t * a.N + (sn < s_end ? sn : s_end - 1);
+                load_row<NPERT>(a.du + row * NPERT, zpre);
+            }
+        };
+        if (sb < s_end) prefetch(sb);
         while (true) {
             const bool fresh = sb < s_end;
             const int pending = qtail - qhead;
@@ -597,8 +612,8 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
 #pragma unroll
                 for (int i = 0; i < Z0; ++i) z[i] = 0.f;
 #pragma unroll
-                for (int i = 0; i < NZ; ++i) z[Z0 + i] = ring[slot * QE + i];
-                wm = __float_as_uint(ring[slot * QE + NZ]);
+                for (int i = 0; i < NPERT; ++i) z[Z0 + i] = ring[slot * QE + i];
+                wm = __float_as_uint(ring[slot * QE + NPERT]);
             } else {
                 const int sidx = sb + lane;
                 on = sidx < s_end;
@@ -616,13 +631,14 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
 #pragma unroll
                     for (int i = 0; i < Z0; ++i) z[i] = 0.f;
                 } else {
-                    const size_t row = (size_t)t * a.N + (on ? sidx : s_end - 1);
-                    if constexpr (Z0 == 0) load_row<n>(a.dx + row * n, z);
-                    else {
+                    static_assert(Z0 == n && NPERT == m, "the parked-sample loop serves the u-only modes");
 #pragma unroll
-                        for (int i = 0; i < n; ++i) z[i] = 0.f;
-                    }
-                    load_row<m>(a.du + row * m, z + n);
+                    for (int i = 0; i < n; ++i) z[i] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < m; ++j) z[n + j] = zpre[j];
+                    const int nb_ = block_of(kt + 1);
+                    const int sbn = nb_ >= 0x3fffffff ? s_end : s_begin + 64 * nb_;
+                    if (sbn < s_end) prefetch(sbn);
                 }
             }
             float xs[n], us[m], fx[n], Bs[TR::FIRST_B ? n * m : 1];
@@ -644,8 +660,8 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
                 if (hard) {
                     const int slot = (qtail + __popcll(bal & ((1ull << lane) - 1ull))) & (kDeferRing - 1);
 #pragma unroll
-                    for (int i = 0; i < NZ; ++i) ring[slot * QE + i] = z[Z0 + i];
-                    ring[slot * QE + NZ] = __uint_as_float(mask);
+                    for (int i = 0; i < NPERT; ++i) ring[slot * QE + i] = z[Z0 + i];
+                    ring[slot * QE + NPERT] = __uint_as_float(mask);
                 }
                 qtail += __popcll(bal);
                 ++kt;
