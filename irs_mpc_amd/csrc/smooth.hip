@@ -581,18 +581,6 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
             return wave == NW - 1 ? 0x3fffffff : NW * rr + (NW - 1) * (k - rr) + wave;
         };
         int sb = s_begin + 64 * block_of(0);
-        // supplied samples: the perturbation of the NEXT fresh trip is loaded while this one computes -- a lone wave
-        // per SIMD has nothing else to cover the ~2000 cycles of a dependent global load at the head of every trip
-        // (measured with in-kernel stamps: 4 050 of a trip's 15 500 cycles were load + primal + accumulate)
-        float zpre[NPERT];
-        auto prefetch = [&](int sbn) {
-            if constexpr (!RNG) {
-                const int sn = sbn + lane;
-                const size_t row = (size_t)t * a.N + (sn < s_end ? sn : s_end - 1);
-                load_row<NPERT>(a.du + row * NPERT, zpre);
-            }
-        };
-        if (sb < s_end) prefetch(sb);
         while (true) {
             const bool fresh = sb < s_end;
             const int pending = qtail - qhead;
@@ -634,11 +622,10 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
                     static_assert(Z0 == n && NPERT == m, "the parked-sample loop serves the u-only modes");
 #pragma unroll
                     for (int i = 0; i < n; ++i) z[i] = 0.f;
-#pragma unroll
-                    for (int j = 0; j < m; ++j) z[n + j] = zpre[j];
-                    const int nb_ = block_of(kt + 1);
-                    const int sbn = nb_ >= 0x3fffffff ? s_end : s_begin + 64 * nb_;
-                    if (sbn < s_end) prefetch(sbn);
+                    // (a register prefetch of the next trip's sample and staging 8 trips through LDS were both measured:
+                    // no change -- the load at the head of a trip is not what a trip waits for)
+                    const size_t row = (size_t)t * a.N + (on ? sidx : s_end - 1);
+                    load_row<NPERT>(a.du + row * NPERT, z + n);
                 }
             }
             float xs[n], us[m], fx[n], Bs[TR::FIRST_B ? n * m : 1];
