@@ -785,6 +785,10 @@ struct PlanarHandModel {
     }
     IRS_HD static constexpr int act(int j) { return 3 + j; }      // internal index of the j-th actuated dof
     IRS_HD static int u_into_x(int j) { return perm(act(j)); }
+    // the impedance gain of the j-th commanded joint: assemble's b[act(j)] = stiffness(j) * (q[act(j)] - u[j]), the ONLY
+    // place u enters the step QP -- lets a caller with a fixed state assemble the geometry once (smooth.hip)
+    template <typename T>
+    IRS_HD static T stiffness(const ModelParams& p, int j) { return (j & 1) ? T(p.v[6]) : T(p.v[5]); }
 
     template <typename S>
     IRS_HD static void step(const ModelParams& p, const S* x_ext, const S* u, S* xn_ext) {
@@ -944,6 +948,8 @@ struct BoxPivotModel {
     IRS_HD static constexpr int perm(int k) { return k == 0 ? 1 : k == 1 ? 3 : k == 2 ? 4 : k == 3 ? 0 : 2; }
     IRS_HD static constexpr int act(int j) { return 3 + j; }
     IRS_HD static int u_into_x(int j) { return perm(act(j)); }
+    template <typename T>
+    IRS_HD static T stiffness(const ModelParams& p, int) { return T(p.v[5]); }      // b[act(j)] = kp (q - u)
 
     template <typename S>
     IRS_HD static void step(const ModelParams& p, const S* x_ext, const S* u, S* xn_ext) {
@@ -1061,6 +1067,8 @@ struct BoxPushModel {
     IRS_HD static constexpr int perm(int k) { return BoxPivotModel::perm(k); }
     IRS_HD static constexpr int act(int j) { return 3 + j; }
     IRS_HD static int u_into_x(int j) { return perm(act(j)); }
+    template <typename T>
+    IRS_HD static T stiffness(const ModelParams& p, int) { return T(p.v[5]); }      // b[act(j)] = kp (q - u)
 
     template <typename S>
     IRS_HD static void step(const ModelParams& p, const S* x_ext, const S* u, S* xn_ext) {
