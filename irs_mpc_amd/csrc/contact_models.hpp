@@ -1167,11 +1167,11 @@ IRS_HD void irs_step_along_finish(const ModelParams& p, const double* x, const d
         constexpr int NX = M::NX, NC = M::NC, NU = M::NU;
         bool good = pre.ok;
         double b[NX], lam[NC];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) b[k] = pre.b0[k];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) b[M::act(j)] = (pre.q[M::act(j)] - u[j]) / pre.Dinv[M::act(j)];
         if (pre.ok) {
-#pragma unroll
-            for (int k = 0; k < NX; ++k) b[k] = pre.b0[k];
-#pragma unroll
-            for (int j = 0; j < NU; ++j) b[M::act(j)] = (pre.q[M::act(j)] - u[j]) / pre.Dinv[M::act(j)];
             double r[NC], y[NC], Db[NX];
 #pragma unroll
             for (int k = 0; k < NX; ++k) Db[k] = b[k] * pre.Dinv[k];
@@ -1237,7 +1237,13 @@ IRS_HD void irs_step_along_finish(const ModelParams& p, const double* x, const d
             for (int i = 0; i < NC; ++i) mk |= pre.act[i] ? (1u << i) : 0u;
             *warm = mk;
         } else {
-            irs_contact_step<M, double>(p, x, u, xn, warm);
+            // a contact made or broken: the full method, warm-started from the previous set as before -- on the
+            // geometry that is already assembled
+            double Wf[NC][NC], lamf[NC], qn[NX];
+            irs_contact_qp_dual_exact<double, NX, NC>(pre.Dinv, b, pre.J, pre.phi, Wf, lamf, warm);
+            irs_contact_qp_primal<double, NX, NC>(pre.q, pre.Dinv, b, pre.J, lamf, qn);
+#pragma unroll
+            for (int k = 0; k < NX; ++k) xn[M::perm(k)] = qn[k];
         }
     } else {
         M::template step<double>(p, x, u, xn);
