@@ -395,10 +395,11 @@ def main():
                          "reference's semantics) or 50 over-relaxed projected sweeps + polish")
     ap.add_argument("--no-graph", action="store_true",
                     help="several ranks: issue the step's launches one by one instead of replaying a HIP graph")
-    ap.add_argument("--collective", default="torch", choices=["torch", "direct"],
-                    help="several ranks: the all-reduce through torch.distributed (default) or issued by the HIP "
-                         "library on a communicator it owns, the whole step captured into a HIP graph inside the "
-                         "library (csrc/collective.hip)")
+    ap.add_argument("--collective", default="auto", choices=["auto", "torch", "direct"],
+                    help="several ranks: the all-reduce issued by the HIP library on an RCCL communicator it owns, "
+                         "the whole step captured into a HIP graph inside the library (csrc/collective.hip; 'direct'), "
+                         "or through torch.distributed ('torch').  'auto' (default) = direct whenever the backend is "
+                         "nccl and every rank can bind RCCL and join the communicator, else torch")
     ap.add_argument("--force-unfused", action="store_true",
                     help="one GPU: time the multi-GPU step (accumulate + all-reduce + solve) with a 1-rank RCCL group")
     args = ap.parse_args()
@@ -442,6 +443,42 @@ def main():
     from irs_mpc_amd import device as dev
     from irs_mpc_amd.distributed import all_reduce_sums, capture_step
 
+    step_info = {}
+    if unfused and args.collective in ("auto", "direct"):
+        # the library-owned communicator is the default data path of a multi-GPU step; every rank must take the
+        # same branch (a rank that fell back alone would issue different collectives and hang the others), so
+        # the ranks agree FIRST on a rank-local pre-check (can RCCL be bound here, is the backend RCCL at all)
+        # and only then enter the collective create; a failure there is agreed on the same way
+        from irs_mpc_amd import _lib as _irs_lib
+        from irs_mpc_amd.distributed import DirectComm
+
+        def _agree(flag):
+            if world == 1:
+                return bool(flag)
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
+
+        why = None
+        if not _agree(args.backend == "nccl" and _irs_lib.load().irs_comm_available() == 1):
+            why = "RCCL not bound on every rank (backend %s)" % args.backend
+        else:
+            comm = None
+            try:
+                comm = DirectComm()
+            except Exception as e:      # noqa: BLE001
+                why = "irs_comm_create failed: " + repr(e)[:160]
+            if _agree(comm is not None):
+                step_info["comm"] = comm
+            else:
+                why = why or "irs_comm_create failed on another rank"
+        if "comm" in step_info:
+            args.collective = "direct"
+        elif args.collective == "direct":
+            raise SystemExit("--collective direct: " + why)
+        else:
+            args.collective, step_info["collective_fallback"] = "torch", why
+
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
@@ -484,8 +521,6 @@ def main():
             el = float(t.item())
         return el, ev_ms
 
-    step_info = {}
-
     def bound_rows(w, x_trj, idx_t):
         """Absolute bound rows of the quasistatic descent around the nominal trajectory x_trj
         (irs_lqr_quasistatic.py:303-325)."""
@@ -519,9 +554,7 @@ def main():
                 plan.run(stream)
         elif args.collective == "direct":
             # the library issues accumulate -> RCCL all-reduce -> solve itself and replays them as one HIP graph
-            from irs_mpc_amd.distributed import CollectiveStep, DirectComm
-            if "comm" not in step_info:
-                step_info["comm"] = DirectComm()
+            from irs_mpc_amd.distributed import CollectiveStep
             plan = dev.SmoothPlan(dm, MODE, x_trj, u_trj, dx=dx, du=du, fuse=True, n_total=n_total)
             tv = plan.out
             cstep = CollectiveStep(plan, step_info["comm"])
@@ -785,6 +818,8 @@ def main():
         if "graph_error" in step_info:
             out["config"]["graph_error"] = step_info["graph_error"]
         out["config"]["collective"] = step_info.get("collective", "torch.distributed all_reduce (%s)" % args.backend)
+        if "collective_fallback" in step_info:
+            out["config"]["collective_fallback"] = step_info["collective_fallback"]
     secondary = world == 1 and not unfused and not args.no_secondary
     if secondary:
         # north_star's N points for the timed workload

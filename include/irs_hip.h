@@ -441,6 +441,7 @@ int irs_descent_run(const irs_descent_call *call, void *stream);
  * (T,P) f64 statistics (RCCL over xGMI) -> solve (every rank, redundantly).  Replaces the reference's ZeroMQ
  * worker pool (zmq_parallel_cmp/array_io.py:6-26, irs_lqr/irs_lqr_quasistatic.py:245-263).  RCCL is bound at
  * run time (the copy torch.distributed's "nccl" backend loaded, if any).
+ *   irs_comm_available   a rank-local, non-collective pre-check a launcher makes before the collective create
  *   irs_comm_unique_id   rank 0 fills 128 bytes (ncclGetUniqueId); the host distributes them to all ranks
  *   irs_comm_create      collective: every rank, with its device current (ncclCommInitRank)
  *   irs_allreduce_sums   in-place f64 SUM all-reduce of `count` doubles on `stream`
@@ -451,6 +452,7 @@ int irs_descent_run(const irs_descent_call *call, void *stream);
  *   irs_step_graph_*     the same three enqueues captured ONCE into a HIP graph (on `stream`, which must not be
  *                        the default stream) and replayed with one call per step: the step is ~70-100 us of
  *                        device work in three launches, which a host issuing them one by one cannot keep fed */
+int irs_comm_available(void);   /* 1 if RCCL could be bound in this process (no communicator is made), else 0 */
 int irs_comm_unique_id(void *id128);
 int irs_comm_create(const void *id128, int nranks, int rank, void **comm);
 int irs_comm_destroy(void *comm);

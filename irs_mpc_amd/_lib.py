@@ -119,6 +119,7 @@ SIGNATURES["irs_tvlqr_box_solve"] = (c_int, [c_int, POINTER(c_double), c_int, c_
 SIGNATURES["irs_least_squares"] = (c_int, [c_int, c_int, c_int, _dp, _dp, _dp, _dp, _dp, c_void_p])
 SIGNATURES["irs_smooth_run"] = (c_int, [POINTER(SmoothCall), c_void_p])
 SIGNATURES["irs_descent_run"] = (c_int, [POINTER(DescentCall), c_void_p])
+SIGNATURES["irs_comm_available"] = (c_int, [])
 SIGNATURES["irs_comm_unique_id"] = (c_int, [c_void_p])
 SIGNATURES["irs_comm_create"] = (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)])
 SIGNATURES["irs_comm_destroy"] = (c_int, [c_void_p])

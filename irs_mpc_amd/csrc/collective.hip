@@ -94,6 +94,8 @@ int enqueue_step(const irs_smooth_call* c, Comm comm, hipStream_t st) {
 
 extern "C" {
 
+int irs_comm_available(void) { return rccl().ok ? 1 : 0; }
+
 int irs_comm_unique_id(void* id128) {
     IRS_CHECK_ARG(id128 != nullptr, "null id buffer");
     int rc = need_rccl("irs_comm_unique_id");

@@ -33,7 +33,7 @@ import torch
 
 from . import device as dev
 from . import distributed as dist_util
-from ._lib import SMOOTH_FIRST_ORDER, SMOOTH_ZERO_ORDER_AB, SMOOTH_ZERO_ORDER_B
+from ._lib import SMOOTH_FIRST_ORDER, SMOOTH_ZERO_ORDER_B
 from .quasistatic_base import QuasistaticOptimizerBase, quasistatic_eval_cost  # noqa: F401
 from .tv_lqr import get_solver
 
@@ -155,53 +155,19 @@ class IrsLqrQuasistatic(QuasistaticOptimizerBase):
     # ---- decouple_AB = False: no example of the reference uses it; served from what the device already
     #      offers (the statistics of the sample pass, the f64 active-set Jacobian), a few small launches more
     def _zero_order_B_full_dev(self, x_trj, u_trj, sums):
-        """calc_B_zero_order without decouple_AB_matrices (quasistatic_dynamics.py:242-266): A = the step's
-        derivative at the nominal point, B = the least-squares fit, read off the (all-reduced) statistics
-        [upper Gram of du | du (f - xb)' | sum du] (include/irs_hip.h), xb = the f32-rounded nominal state."""
-        n, m, T = self.dim_x, self.dim_u, self.T
-        Ae, Be, ce = self._dm.exact_linearize(x_trj, u_trj)
-        x, u = x_trj[:-1], u_trj
-        f = ce + torch.einsum("tij,tj->ti", Ae, x) + torch.einsum("tij,tj->ti", Be, u)
-        iu = torch.triu_indices(m, m, device=sums.device)
-        ng = iu.shape[1]
-        G = torch.zeros((T, m, m), dtype=sums.dtype, device=sums.device)
-        G[:, iu[0], iu[1]] = sums[:, :ng]
-        G = G + torch.triu(G, 1).transpose(1, 2)
-        H = sums[:, ng:ng + m * n].reshape(T, m, n)
-        sz = sums[:, ng + m * n:ng + m * n + m]
-        xb = x.to(torch.float32).to(sums.dtype)
-        H = H - sz[:, :, None] * (f - xb)[:, None, :]
-        Bt = torch.linalg.solve(G, H).transpose(1, 2).contiguous()
-        ct = (f - torch.einsum("tij,tj->ti", Ae, x) - torch.einsum("tij,tj->ti", Bt, u)).contiguous()
-        return Ae, Bt, ct
+        """calc_B_zero_order without decouple_AB_matrices (quasistatic_dynamics.py:242-266), read off the
+        (all-reduced) statistics of the sample pass: `QuasistaticDeviceDynamics.zero_order_B_from_sums_dev`."""
+        At, Bt, ct, info = self.q_dynamics.zero_order_B_from_sums_dev(x_trj[:-1], u_trj, sums)
+        self._smooth_info = self._smooth_info | info
+        return At, Bt, ct
 
     def _first_order_full_dev(self, x_trj, u_trj, std_u):
         """calc_AB_first_order without decouple_AB_matrices (quasistatic_dynamics.py:193-208): the mean over
-        the u-perturbed samples of the FULL [Dq_nextDq | Dq_nextDqa_cmd], from the f64 `jacobian_xu_batch`
-        lanes (one per sample), time step by time step; ranks own shards of the samples and all-reduce the
-        (T, n (n+m)) sums."""
-        rank, world = dist_util.rank_world()
-        N, n, m, T = self.num_samples, self.dim_x, self.dim_u, self.T
-        lo, hi = dist_util.shard_range(N, rank, world)
-        seed = getattr(self.params, "device_rng_seed", None)
-        if seed is None:
-            du = np.stack([np.random.normal(0, std_u, size=[N, m]) for _ in range(T)])
-            du = dev.to_dev(np.ascontiguousarray(du[:, lo:hi]))
-        else:
-            _, du32 = self._dm.rng_samples(T, hi - lo, np.zeros(n), std_u, int(seed), self.current_iter,
-                                           sample_offset=lo)
-            du = du32.to(dev.F64)
-        sums = torch.zeros((T, n * (n + m)), dtype=dev.F64, device=x_trj.device)
-        for t in range(T):
-            X = x_trj[t].expand(hi - lo, n).contiguous()
-            U = (u_trj[t] + du[t]).contiguous()
-            sums[t] = self._dm.jacobian_xu_batch(X, U).sum(0).reshape(-1)
-        dist_util.all_reduce_sums(sums)
-        AB = (sums / float(N)).reshape(T, n, n + m)
-        At, Bt = AB[:, :, :n].contiguous(), AB[:, :, n:].contiguous()
-        x_next = self._dm.dynamics_batch(x_trj[:-1].contiguous(), u_trj)
-        ct = (x_next - torch.einsum("tij,tj->ti", At, x_trj[:-1]) - torch.einsum("tij,tj->ti", Bt, u_trj)).contiguous()
-        self._smooth_info = torch.zeros(T, dtype=torch.int32, device=x_trj.device)
+        the u-perturbed samples of the FULL [Dq_nextDq | Dq_nextDqa_cmd] -- `calc_AB_batch_dev` over the T
+        nominal points (f64 Jacobian lanes, one per sample; ranks own shards and all-reduce the sums)."""
+        At, Bt, ct, self._smooth_info = self.q_dynamics.calc_AB_batch_dev(
+            x_trj[:-1], u_trj, self.num_samples, std_u, "first_order",
+            seed=getattr(self.params, "device_rng_seed", None), it=self.current_iter)
         return At, Bt, ct
 
     def _exact_dev(self, x_trj, u_trj):
@@ -218,40 +184,16 @@ class IrsLqrQuasistatic(QuasistaticOptimizerBase):
             ct = (f - torch.einsum("tij,tj->ti", At, x_trj[:-1]) - torch.einsum("tij,tj->ti", Bt, u_trj)).contiguous()
         return At, Bt, ct
 
-    # calc_AB_zero_order's defaults (quasistatic_dynamics.py:268-272)
-    ZERO_ORDER_AB_STD_X = 1e-3
-    ZERO_ORDER_AB_DAMP = 1e-2
-
     def _zero_order_AB_dev(self, x_trj, u_trj, std_u):
         """gradient_mode "zero_order_AB" (quasistatic_dynamics.py:268-300): x AND u are perturbed
-        (dx ~ N(0, 1e-3), drawn first, as there), and `damp`-weighted identity rows regularise the
-        least squares.  Those rows add damp^2 to the Gram diagonal and nothing to the cross term, so
-        the path is: accumulate the statistics, add damp^2 on the diagonal entries of the (all-reduced)
-        sums, solve; then decouple_AB_matrices (:275-284) and c_t = f - A x - B u with the decoupled
-        pair, f recovered from the undecoupled solve."""
-        rank, world = dist_util.rank_world()
-        N, n, m, T = self.num_samples, self.dim_x, self.dim_u, self.T
-        lo, hi = dist_util.shard_range(N, rank, world)
-        seed = getattr(self.params, "device_rng_seed", None)
-        if seed is None:
-            dx, du = [], []
-            for _ in range(T):
-                dx.append(np.random.normal(0, self.ZERO_ORDER_AB_STD_X, size=[N, n]))
-                du.append(np.random.normal(0, std_u, size=[N, m]))
-            dxd = dev.to_dev(np.ascontiguousarray(np.stack(dx)[:, lo:hi], np.float32), dev.F32)
-            dud = dev.to_dev(np.ascontiguousarray(np.stack(du)[:, lo:hi], np.float32), dev.F32)
-            sums = self._dm.smooth_accumulate(SMOOTH_ZERO_ORDER_AB, x_trj, u_trj, dxd, dud)
-        else:
-            sums = self._dm.smooth_accumulate_rng(SMOOTH_ZERO_ORDER_AB, x_trj, u_trj, hi - lo,
-                                                  np.full(n, self.ZERO_ORDER_AB_STD_X), std_u, int(seed),
-                                                  self.current_iter, sample_offset=lo)
-        dist_util.all_reduce_sums(sums)
-        d = n + m
-        diag = torch.as_tensor([i * d - i * (i - 1) // 2 for i in range(d)], device=sums.device)
-        sums[:, diag] += self.ZERO_ORDER_AB_DAMP ** 2
-        ws = self._dm._workspace(SMOOTH_ZERO_ORDER_AB, T, hi - lo, x_trj.device)
-        At, Bt, ct, info = self._dm.smooth_finalize(SMOOTH_ZERO_ORDER_AB, N, x_trj, u_trj, sums, workspace=ws)
-        self._smooth_info = info
+        (dx ~ N(0, 1e-3), drawn first, as there), `damp`-weighted identity rows regularise the least squares
+        (`calc_AB_batch_dev`: accumulate the statistics, all-reduce, damp^2 on the Gram diagonal, solve); then
+        decouple_AB_matrices (:275-284) and c_t = f - A x - B u with the decoupled pair, f recovered from the
+        undecoupled solve."""
+        n, m = self.dim_x, self.dim_u
+        At, Bt, ct, self._smooth_info = self.q_dynamics.calc_AB_batch_dev(
+            x_trj[:-1], u_trj, self.num_samples, std_u, "zero_order_AB",
+            seed=getattr(self.params, "device_rng_seed", None), it=self.current_iter)
         if not self.decouple_AB:
             return At, Bt, ct
         # f = c + A x + B u with the fitted pair; then overwrite the structure and rebuild c

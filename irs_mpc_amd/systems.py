@@ -1,7 +1,10 @@
 """Device-backed twins of the reference's analytic example plugins."""
 import numpy as np
+import torch
 
-from ._lib import (MODEL_BICYCLE, MODEL_BOX_ON_BOX, MODEL_BOX_PIVOT, MODEL_BOX_PUSH, MODEL_PENDULUM,
+from . import device as dev
+from ._lib import (SMOOTH_ZERO_ORDER_AB, SMOOTH_ZERO_ORDER_B,
+                   MODEL_BICYCLE, MODEL_BOX_ON_BOX, MODEL_BOX_PIVOT, MODEL_BOX_PUSH, MODEL_PENDULUM,
                    MODEL_BOX_PIVOT_EXACT, MODEL_BOX_PUSH_EXACT, MODEL_PLANAR_HAND, MODEL_PLANAR_HAND_EXACT,
                    MODEL_QUADROTOR, MODEL_THREE_CART)
 from .dynamical_system import DynamicalSystem
@@ -80,6 +83,138 @@ class QuasistaticDeviceDynamics(DynamicalSystem):
     def calc_AB_exact(self, x_nominal, u_nominal):
         """quasistatic_dynamics.py:189-191."""
         return self.jacobian_xu(x_nominal, u_nominal)
+
+    # ---- the randomised-smoothing estimators (quasistatic_dynamics.py:193-300) ---------------------------
+    # Same names, arguments, draws (np.random.normal from the global generator, in the reference's order:
+    # per nominal point, dx before du) and return layout `[A | B]`, (n, n+m) -- the UNDECOUPLED pair, as in
+    # the reference, where IrsLqrQuasistatic.decouple_AB_matrices comes afterwards.  Underneath, each is
+    # the launch(es) `calc_AB_batch` makes over all nominal points at once.
+    ZERO_ORDER_AB_STD_X = 1e-3      # calc_AB_zero_order's defaults (quasistatic_dynamics.py:270-271)
+    ZERO_ORDER_AB_DAMP = 1e-2
+    AB_MODES = ("first_order", "zero_order_B", "zero_order_AB", "exact")
+
+    def calc_AB_first_order(self, x_nominal, u_nominal, n_samples, std_u):
+        """quasistatic_dynamics.py:193-208: the mean over `n_samples` u-perturbed steps of the simulator's
+        `[Dq_nextDq | Dq_nextDqa_cmd]`."""
+        return self.calc_AB_batch(np.asarray(x_nominal, float)[None], np.asarray(u_nominal, float)[None],
+                                  n_samples, std_u, "first_order")[0]
+
+    def calc_B_zero_order(self, x_nominal, u_nominal, n_samples, std_u):
+        """quasistatic_dynamics.py:242-266: B by least squares on u-perturbed steps, A = `Dq_nextDq` at the
+        nominal point."""
+        return self.calc_AB_batch(np.asarray(x_nominal, float)[None], np.asarray(u_nominal, float)[None],
+                                  n_samples, std_u, "zero_order_B")[0]
+
+    def calc_AB_zero_order(self, x_nominal, u_nominal, n_samples, std_u, std_x=1e-3, damp=1e-2):
+        """quasistatic_dynamics.py:268-300: A and B by least squares on (x, u)-perturbed steps with `damp`
+        identity rows appended."""
+        return self.calc_AB_batch(np.asarray(x_nominal, float)[None], np.asarray(u_nominal, float)[None],
+                                  n_samples, std_u, "zero_order_AB", std_x=std_x, damp=damp)[0]
+
+    def calc_AB_batch(self, x_nominals, u_nominals, n_samples, std_u, mode, std_x=1e-3, damp=1e-2):
+        """quasistatic_dynamics.py:210-240: `ABhat_list` (k, n, n+m) for k nominal points; `mode` one of
+        "first_order", "zero_order_B", "zero_order_AB", "exact" (anything else: the reference's
+        RuntimeError, :238)."""
+        x = dev.to_dev(np.atleast_2d(np.asarray(x_nominals, float)))
+        u = dev.to_dev(np.atleast_2d(np.asarray(u_nominals, float)))
+        At, Bt, _, info = self.calc_AB_batch_dev(x, u, n_samples, std_u, mode, std_x=std_x, damp=damp)
+        if bool((info != 0).any().item()):
+            raise ValueError("randomized-smoothing least squares is rank deficient or met a non-finite sample")
+        return torch.cat([At, Bt], dim=2).cpu().numpy()
+
+    def calc_AB_batch_dev(self, x, u, n_samples, std_u, mode, std_x=1e-3, damp=1e-2, seed=None, it=1):
+        """`calc_AB_batch` on device tensors: x (k,n), u (k,m) f64 -> (At (k,n,n), Bt (k,n,m), ct (k,n), info (k))
+        with c = f(x,u) - A x - B u.  One sample-pass launch over all k x n_samples perturbed steps (zero-order
+        modes: + the solve on the sums; "zero_order_B": + one launch of k f64 lanes for A; "first_order": the
+        f64 Jacobian lanes, one per sample).  `seed` None: the perturbations are the reference's host draws;
+        an int: drawn on the device (Philox, iteration counter `it`).  With torch.distributed initialised every
+        rank draws the same samples, keeps its shard and the statistics are all-reduced once."""
+        from . import distributed as dist_util
+        if mode not in self.AB_MODES:
+            raise RuntimeError(f"AB mode {mode} is not supported.")                 # quasistatic_dynamics.py:238
+        dm, n, m, k = self.dm(), self.dim_x, self.dim_u, x.shape[0]
+        N = int(n_samples)
+        std_u = np.broadcast_to(np.asarray(std_u, float), (m,))
+        zero_info = torch.zeros(k, dtype=torch.int32, device=x.device)
+        if mode == "exact":
+            return (*dm.exact_linearize(x, u), zero_info)
+        rank, world = dist_util.rank_world()
+        lo, hi = dist_util.shard_range(N, rank, world)
+
+        def c_of(At, Bt):
+            f = dm.dynamics_batch(x, u)
+            return (f - torch.einsum("tij,tj->ti", At, x) - torch.einsum("tij,tj->ti", Bt, u)).contiguous()
+
+        if mode == "first_order":
+            if seed is None:
+                du = np.stack([np.random.normal(0, std_u, size=[N, m]) for _ in range(k)])
+                du = dev.to_dev(np.ascontiguousarray(du[:, lo:hi]))
+            else:
+                du = dm.rng_samples(k, hi - lo, np.zeros(n), std_u, int(seed), int(it), sample_offset=lo)[1].to(dev.F64)
+            sums = torch.zeros((k, n * (n + m)), dtype=dev.F64, device=x.device)
+            step = max(1, 200000 // max(hi - lo, 1))          # <= 2e5 Jacobian lanes (123 MB of f64) per launch
+            for a in range(0, k, step):
+                b = min(k, a + step)
+                X = x[a:b, None, :].expand(b - a, hi - lo, n).reshape(-1, n).contiguous()
+                U = (u[a:b, None, :] + du[a:b]).reshape(-1, m).contiguous()
+                sums[a:b] = dm.jacobian_xu_batch(X, U).reshape(b - a, hi - lo, -1).sum(1)
+            dist_util.all_reduce_sums(sums)
+            AB = (sums / float(N)).reshape(k, n, n + m)
+            At, Bt = AB[:, :, :n].contiguous(), AB[:, :, n:].contiguous()
+            return At, Bt, c_of(At, Bt), zero_info
+
+        if mode == "zero_order_AB":
+            MODE = SMOOTH_ZERO_ORDER_AB
+            sx = np.broadcast_to(np.asarray(std_x, float), (n,))
+            if seed is None:
+                dxs, dus = [], []
+                for _ in range(k):                                                   # :282-283: dx first
+                    dxs.append(np.random.normal(0, sx, size=[N, n]))
+                    dus.append(np.random.normal(0, std_u, size=[N, m]))
+                dxd = dev.to_dev(np.ascontiguousarray(np.stack(dxs)[:, lo:hi], np.float32), dev.F32)
+                dud = dev.to_dev(np.ascontiguousarray(np.stack(dus)[:, lo:hi], np.float32), dev.F32)
+                sums = dm.smooth_accumulate(MODE, x, u, dxd, dud)
+            else:
+                sums = dm.smooth_accumulate_rng(MODE, x, u, hi - lo, sx, std_u, int(seed), int(it), sample_offset=lo)
+            dist_util.all_reduce_sums(sums)
+            # the `damp` identity rows add damp^2 to the Gram diagonal and nothing to the cross term
+            d = n + m
+            diag = torch.as_tensor([i * d - i * (i - 1) // 2 for i in range(d)], device=sums.device)
+            sums[:, diag] += float(damp) ** 2
+            ws = dm._workspace(MODE, k, hi - lo, x.device)
+            return dm.smooth_finalize(MODE, N, x, u, sums, workspace=ws)
+
+        # "zero_order_B": statistics [upper Gram of du | du (f - xb)' | sum du], xb = the f32-rounded nominal state
+        MODE = SMOOTH_ZERO_ORDER_B
+        if seed is None:
+            du = np.stack([np.random.normal(0, std_u, size=[N, m]) for _ in range(k)])
+            du = dev.to_dev(np.ascontiguousarray(du[:, lo:hi], np.float32), dev.F32)
+            sums = dm.smooth_accumulate(MODE, x, u, None, du)
+        else:
+            sums = dm.smooth_accumulate_rng(MODE, x, u, hi - lo, None, std_u, int(seed), int(it), sample_offset=lo)
+        dist_util.all_reduce_sums(sums)
+        return self.zero_order_B_from_sums_dev(x, u, sums)
+
+    def zero_order_B_from_sums_dev(self, x, u, sums):
+        """calc_B_zero_order from the (all-reduced) ZERO_ORDER_B statistics of a contact model
+        (include/irs_hip.h): B = the least-squares fit, A = the step's derivative at the nominal point."""
+        dm, n, m, k = self.dm(), self.dim_x, self.dim_u, x.shape[0]
+        Ae, Be, ce = dm.exact_linearize(x, u)
+        f = ce + torch.einsum("tij,tj->ti", Ae, x) + torch.einsum("tij,tj->ti", Be, u)
+        iu = torch.triu_indices(m, m, device=sums.device)
+        ng = iu.shape[1]
+        G = torch.zeros((k, m, m), dtype=sums.dtype, device=sums.device)
+        G[:, iu[0], iu[1]] = sums[:, :ng]
+        G = G + torch.triu(G, 1).transpose(1, 2)
+        H = sums[:, ng:ng + m * n].reshape(k, m, n)
+        sz = sums[:, ng + m * n:ng + m * n + m]
+        xb = x.to(torch.float32).to(sums.dtype)
+        H = H - sz[:, :, None] * (f - xb)[:, None, :]
+        Bt, info = torch.linalg.solve_ex(G, H)
+        Bt = Bt.transpose(1, 2).contiguous()
+        bad = (info != 0) | ~torch.isfinite(Bt).reshape(k, -1).all(1)
+        ct = (f - torch.einsum("tij,tj->ti", Ae, x) - torch.einsum("tij,tj->ti", Bt, u)).contiguous()
+        return Ae, Bt, ct, bad.to(torch.int32)
 
     def _finish_bookkeeping(self):
         self.models_all = self.models_unactuated + self.models_actuated

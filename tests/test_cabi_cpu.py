@@ -120,3 +120,51 @@ def test_no_gpu_fails_loudly():
     from irs_mpc_amd import PendulumDynamics
     with pytest.raises(RuntimeError, match="needs an AMD GPU"):
         PendulumDynamics(0.05).dynamics_batch(np.zeros((1, 2)), np.zeros((1, 1)))
+
+
+def test_compat_shim_resolves_the_reference_scripts_imports():
+    """f4: examples/compat lets the TEXT of the reference's analytic example scripts run with only sys.path
+    changed -- every `from irs_lqr... import ...` / `from <system>_dynamics import ...` line of those scripts must
+    resolve to a device-backed twin.  The names are listed here (read off examples/{pendulum,quadrotor,bicycle,
+    three_cart}/*.py of the reference); when the reference tree is present (this container, not the GPU box) its
+    scripts are scanned as well so that the list cannot go stale."""
+    import importlib
+    import os
+    import re
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shim = os.path.join(root, "examples", "compat")
+    wanted = {("irs_lqr.all", n) for n in ("IrsLqrParameters", "IrsLqrZeroOrder", "IrsLqrFirstOrder", "IrsLqrExact",
+                                            "CemParameters", "CrossEntropyMethod")}
+    wanted |= {("irs_lqr.irs_lqr", "IrsLqr"), ("pendulum_dynamics", "PendulumDynamics"),
+               ("quadrotor_dynamics", "QuadrotorDynamics"), ("bicycle_dynamics", "BicycleDynamics"),
+               ("three_cart_dynamics", "ThreeCartDynamics"),
+               ("irs_lqr.irs_lqr_quasistatic", "IrsLqrQuasistatic"), ("irs_lqr.irs_lqr_quasistatic", "IrsLqrQuasistaticParameters"),
+               ("irs_lqr.tv_lqr", "solve_tvlqr"), ("irs_lqr.tv_lqr", "get_solver"),
+               ("irs_lqr.dynamical_system", "DynamicalSystem")}
+    ref = "/root/reference/examples"
+    if os.path.isdir(ref):
+        pat = re.compile(r"^from\s+(irs_lqr(?:\.\w+)*|\w+_dynamics)\s+import\s+(.+)$")
+        for sysname in ("pendulum", "quadrotor", "bicycle", "three_cart"):
+            for fn in sorted(os.listdir(os.path.join(ref, sysname))):
+                if not fn.endswith(".py") or fn.endswith("_dynamics.py") or "animation" in fn or "drake" in fn \
+                        or "simulation" in fn or fn == "pendulum_nn.py":
+                    continue
+                for line in open(os.path.join(ref, sysname, fn)):
+                    mm = pat.match(line.strip())
+                    if mm:
+                        wanted |= {(mm.group(1), nm.strip()) for nm in mm.group(2).split(",")}
+    sys.path.insert(0, shim)
+    try:
+        for mod in [m for m in sys.modules if m == "irs_lqr" or m.startswith("irs_lqr.")]:
+            del sys.modules[mod]
+        import irs_mpc_amd
+        for mod, name in sorted(wanted):
+            m = importlib.import_module(mod)
+            assert hasattr(m, name), (mod, name)
+            assert getattr(m, name).__module__.startswith("irs_mpc_amd"), (mod, name)
+        assert importlib.import_module("irs_lqr.all").IrsLqrZeroOrder is irs_mpc_amd.IrsLqrZeroOrder
+    finally:
+        sys.path.remove(shim)
+        for mod in [m for m in sys.modules if m == "irs_lqr" or m.startswith("irs_lqr.") or m.endswith("_dynamics")]:
+            del sys.modules[mod]
