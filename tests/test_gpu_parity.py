@@ -2158,9 +2158,9 @@ def test_calc_AB_estimator_methods_vs_oracle(amd, system):
         np.testing.assert_allclose(got[:, :, n:], Bo, rtol=0, atol=tolB, err_msg=mode)
     # the single-point methods are the batch of one point on the same draws
     np.random.seed(11)
-    np.testing.assert_allclose(sys_d.calc_AB_first_order(x[0], u[0], N, std_u),
-                               orc.first_order_B_decoupled(sys_o, xp[:2], u[:1], draws("first_order")[1][:1],
-                                                           decouple=False)[0][0], rtol=0, atol=1e-8, err_msg="A")
+    AB = sys_d.calc_AB_first_order(x[0], u[0], N, std_u)
+    Ao, Bo, _ = orc.first_order_B_decoupled(sys_o, xp[:2], u[:1], draws("first_order")[1][:1], decouple=False)
+    np.testing.assert_allclose(AB, np.hstack([Ao[0], Bo[0]]), rtol=0, atol=1e-8)
     np.random.seed(11)
     AB = sys_d.calc_B_zero_order(x[0], u[0], N, std_u)
     Ao, Bo, _ = orc.zero_order_B_decoupled(sys_o, xp[:2], u[:1], f32(draws("zero_order_B")[1][:1]), decouple=False)

@@ -18,7 +18,7 @@ SMOOTH_EXTRA = "-ffinite-math-only -fno-signed-zeros"       # csrc/Makefile: smo
 def main():
     src = sys.argv[1]
     filt = sys.argv[2] if len(sys.argv) > 2 else "."
-    extra = SMOOTH_EXTRA if src.endswith("smooth.hip") else ""
+    extra = SMOOTH_EXTRA if src.endswith("smooth.hip") else (SMOOTH_EXTRA + " -fno-slp-vectorize" if src.endswith("smooth_ug.hip") else "")
     cmd = "/opt/rocm/bin/hipcc %s %s -Rpass-analysis=kernel-resource-usage -c %s -o /tmp/kernel_resources.o" % (
         FLAGS, extra, src)
     out = subprocess.run(cmd, shell=True, capture_output=True, text=True).stderr
@@ -34,7 +34,7 @@ def main():
             rows[cur][m.group(1)] = int(m.group(2))
     names = list(rows)
     dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
-    keys = ("VGPRs", "AGPRs", "ScratchSize", "Occupancy", "VGPRs Spill")
+    keys = ("VGPRs", "AGPRs", "SGPRs", "ScratchSize", "Occupancy", "VGPRs Spill", "SGPRs Spill", "LDS Size")
     for name, k in zip(dem, names):
         if re.search(filt, name):
             print(name.replace("(anonymous namespace)::", "")[:100], {x: rows[k].get(x) for x in keys})
