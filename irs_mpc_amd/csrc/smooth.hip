@@ -178,6 +178,11 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
             if constexpr (TR::FIRST_B) {
 #pragma unroll
                 for (int q = 0; q < n * m; ++q) acc[q] += on ? Bs[q] : 0.f;
+                // the derivative of a step whose command is NaN / Inf is finite (no row tests active): mark it
+                bool nf = false;
+#pragma unroll
+                for (int j = 0; j < m; ++j) nf = nf || irs_nonfinite_bits(z[n + j]);
+                if (on && nf) acc[0] = irs_poison();
             } else {
                 float zz[NZ], df[n];
 #pragma unroll
@@ -388,6 +393,10 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
                     irs_contact_step_grad<Model, float, false>(a.p, xs, us, fx, Bs, nullptr);
 #pragma unroll
                     for (int q = 0; q < n * m; ++q) acc[q] += Bs[q];
+                    bool nf = false;
+#pragma unroll
+                    for (int j = 0; j < m; ++j) nf = nf || irs_nonfinite_bits(z[n + j]);
+                    if (nf) acc[0] = irs_poison();
                 } else if constexpr (MODE == IRS_SMOOTH_FIRST_ORDER) {
                     float J[n * d];
                     model_jacobian<Model, float>(a.p, xs, us, fx, J);
@@ -701,7 +710,7 @@ int smooth_common(int model, const double* params, int n_params, int mode, int T
         a.block = 512;
         a.chunk = a.chunk0 = 0;
         a.wg0_rr = 0x7fffffff;
-        { static int dg = getenv("IRS_DIAG") ? atoi(getenv("IRS_DIAG")) : 0; a.diag = dg; }
+        a.diag = getenv("IRS_DIAG") ? atoi(getenv("IRS_DIAG")) : 0;      // timing experiments only
         a.counters = static_cast<int*>(workspace);
         a.fnom = reinterpret_cast<double*>(static_cast<char*>(workspace) + kCounterBytes);
         a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + kCounterBytes + fnom_bytes(T));

@@ -84,6 +84,20 @@ struct SmoothTraits {
 };
 
 
+// Non-finite perturbations under -ffinite-math-only (these translation units are built with it): a clamp or a compare
+// inside a contact step can swallow a NaN / Inf sample, and the optimiser may assume float values finite, so both the
+// test and the marker go through opaque register moves.  A marked accumulator makes the solve report info != 0.
+__device__ __forceinline__ bool irs_nonfinite_bits(float v) {
+    unsigned bits = __float_as_uint(v);
+    asm volatile("" : "+v"(bits));
+    return (bits & 0x7f800000u) == 0x7f800000u;
+}
+__device__ __forceinline__ float irs_poison() {
+    unsigned b = 0x7fc00000u;
+    asm volatile("" : "+v"(b));
+    return __uint_as_float(b);
+}
+
 template <int K>
 __device__ __forceinline__ void load_row(const float* __restrict__ ptr, float* out) {
     if constexpr (K % 4 == 0) {
@@ -413,7 +427,7 @@ __device__ __forceinline__ void smooth_finish(const SmoothArgs& a, float* red, d
             for (int w = 1; w < NW; ++w) s += red[w * TR::PP + q];
             tot[q] = (double)s;
         }
-    } else if constexpr (BLOCK <= 512) {
+    } else if constexpr (BLOCK <= 512 || FNOM_ONLY) {
         // publish this workgroup's partial sums: 16-byte write-through (sc1) stores, one
         // row of P4 floats per workgroup (few wide fabric writes instead of P narrow ones)
         for (int q = tid; q < P; q += BLOCK) {

@@ -9,7 +9,7 @@
 // linearly in du.  Its dual  min_{lam >= 0} 1/2 lam'W lam + r'lam  has ONE Hessian W = J D^-1 J' per timestep and
 // r = r0 + C du.  The general kernel (smooth.hip) carries J, W and a masked LDL' of W_AA in the registers of every
 // lane (388 registers: one wave per SIMD) and re-factorises per sample.  Here
-//   * everything uniform lives in scalar registers / LDS (W, r0, C, J D^-1);
+//   * everything uniform lives in LDS (C, J D^-1, the table) or in ONE set of registers per lane (W, r0: 52);
 //   * the workgroup tabulates, once, for ALL 2^8 candidate active sets A the map  r -> [lam_A ; slacks off A]
 //     (G_A: rows of -W_AA^-1 on A -- masked LDL' in row order with the same pivot rule as
 //     irs_contact_qp_dual_exact, a dependent row drops out -- and of I + W M off A): 256 x 64 floats in LDS;
@@ -36,13 +36,20 @@ namespace {
 #define IRS_UG_SWEEPS 6
 #endif
 #ifndef IRS_UG_PDAS
-#define IRS_UG_PDAS 5
+#define IRS_UG_PDAS 4
 #endif
-constexpr int kUgBlock = 512;
+#ifndef IRS_UG_BLOCK
+#define IRS_UG_BLOCK 512
+#endif
+constexpr int kUgBlock = IRS_UG_BLOCK;
 constexpr int kUgSweeps = IRS_UG_SWEEPS;      // projected sweeps that guess the active set
 constexpr int kUgPdas = IRS_UG_PDAS;          // primal-dual active-set iterations of the first attempt
 constexpr int kUgTabStride = 76;              // floats per table entry: 64 (G', column-major) + 8 (tau: 1 off the reduced
                                               // set, 0 on it) + the reduced set + pad; 304 B: 16-byte aligned rows
+#ifndef IRS_UG_NOM_ROUNDS
+#define IRS_UG_NOM_ROUNDS 3
+#endif
+constexpr int kUgNomRounds = IRS_UG_NOM_ROUNDS;   // sample rounds the nominal wave sits out (its f64 step takes about that long)
 constexpr int kUgRing = 128;                  // parked samples per wave: < 64 waiting + <= 64 new ones
 
 template <class Model>
@@ -53,6 +60,7 @@ struct alignas(16) UgLds {
     float invw[NC];           // omega / W_ii
     float Wd[NC];             // W_ii
     float r0[NC];             // phi - J D^-1 b(u_t)
+    float phi[NC];
     float C[m][NC];           // r = r0 + sum_j C[j][:] du_j
     float JD[n][NC];          // JD[k][c] = J[c][k] D^-1_k   (primal recovery: dq_k = sum_c JD[k][c] lam_c - Db_k)
     float Jc[NC][n];          // J
@@ -62,19 +70,11 @@ struct alignas(16) UgLds {
     float q[n];
 };
 
-// a NaN the optimiser cannot see through (this file is built with -ffinite-math-only, under which arithmetic on a
-// literal NaN is undefined and may be folded away): what marks statistics that met a non-finite perturbation
-__device__ __forceinline__ float ug_poison() {
-    unsigned b = 0x7fc00000u;
-    asm volatile("" : "+v"(b));
-    return __uint_as_float(b);
-}
-
 __device__ __forceinline__ float ug_uniform(float v) {
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
 
-// what the sample loop keeps in scalar registers
+// the uniform operands the sample loop keeps in registers
 template <int NC>
 struct UgUni {
     float W[NC * (NC + 1) / 2];
@@ -139,13 +139,13 @@ __device__ __forceinline__ float ug_rhs(const UgUni<Model::NC>& U, const UgLds<M
 // optimum (KKT certified); false: `a` is the set the iteration stopped on (a warm start for ug_full).
 template <class Model>
 __device__ __forceinline__ bool ug_try(const UgUni<Model::NC>& U, const UgLds<Model>& S, const float* r, float tolv,
-                                       float* lam, unsigned& a_out) {
+                                       float* lam, unsigned& a_out, int diag = 0) {
     constexpr int NC = Model::NC;
     float g[NC];
 #pragma unroll
     for (int i = 0; i < NC; ++i) { lam[i] = 0.f; g[i] = r[i]; }
 #pragma unroll 2
-    for (int sw = 0; sw < kUgSweeps; ++sw) {
+    for (int sw = 0; sw < ((diag & 64) ? 0 : kUgSweeps); ++sw) {
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const float nw = fmaxf(fmaf(-g[i], U.invw[i], lam[i]), 0.f);
@@ -158,14 +158,16 @@ __device__ __forceinline__ bool ug_try(const UgUni<Model::NC>& U, const UgLds<Mo
     unsigned a = 0u;
 #pragma unroll
     for (int i = 0; i < NC; ++i) a |= (lam[i] > 0.f) ? (1u << i) : 0u;
-    bool done = false;
+    bool done = (diag & 32) != 0;
     for (int it = 0; it < kUgPdas; ++it) {
         float v[NC], tau[NC];
         const unsigned ap = ug_lookup<Model>(S, a, r, tolv, v, tau);
         // rows that are not optimal flip: a multiplier <= 0 leaves the set, a slack < -tol joins it
+        // (the sign bits, shifted in one v_alignbit each: row 0 ends in bit 0.  A multiplier of exactly +0 stays: it
+        // satisfies the KKT conditions as it is)
         unsigned bad = 0u;
 #pragma unroll
-        for (int i = 0; i < NC; ++i) bad |= !(v[i] > 0.f) ? (1u << i) : 0u;
+        for (int i = NC - 1; i >= 0; --i) bad = __builtin_amdgcn_alignbit(bad, __float_as_uint(v[i]), 31);
         if (!done) {
             if (bad == 0u) {
 #pragma unroll
@@ -186,7 +188,8 @@ __device__ __forceinline__ bool ug_try(const UgUni<Model::NC>& U, const UgLds<Mo
 //   loop: p = most violated row off A; u = G_A W[:,p] gives rho = -u on A and the slack rates s = u off A in one
 //   product; step to the first of { slack_p = 0 (p joins), some lam_i = 0 (i leaves) }.  Finite, no cycling.
 template <class Model>
-__device__ __forceinline__ void ug_full(const UgLds<Model>& S, const float* r, float tolv, unsigned a, float* lam) {
+__device__ __forceinline__ void ug_full(const UgLds<Model>& S, const float* r, float tolv, unsigned a, float* lam,
+                                        int cap = 4 * Model::NC) {
     constexpr int NC = Model::NC;
     constexpr float kBig = 3.0e38f, piv_rel = 1e-5f;
     float g[NC];
@@ -215,7 +218,7 @@ __device__ __forceinline__ void ug_full(const UgLds<Model>& S, const float* r, f
     }
     int p = -1;
     bool done = false;
-    for (int it = 0; it < 4 * NC; ++it) {
+    for (int it = 0; it < cap; ++it) {
         if (!done && p < 0) {
             float vmin = kBig;
             int c = 0;
@@ -480,6 +483,23 @@ __device__ __forceinline__ void ug_nominal(const SmoothArgs& a, const UgUni<Mode
     }
 }
 
+// -DIRS_UG_STAMPS (tuning builds only): s_memtime at the phase boundaries of every workgroup -> a device buffer that
+// irs_debug_ug_stamps copies out (tools/ug_stamps.py)
+#ifdef IRS_UG_STAMPS
+constexpr int kUgStampSlots = 12, kUgStampWgs = 2048;
+__device__ unsigned long long ug_stamps[kUgStampWgs * kUgStampSlots];
+#define UG_STAMP(slot)                                                                          \
+    do {                                                                                        \
+        if ((threadIdx.x & 63) == 0) {                                                          \
+            const int wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                \
+            if (wg_ < kUgStampWgs && ((slot) < 8 ? threadIdx.x == 0 : true))                    \
+                ug_stamps[wg_ * kUgStampSlots + (slot)] = __builtin_amdgcn_s_memtime();         \
+        }                                                                                       \
+    } while (0)
+#else
+#define UG_STAMP(slot) do {} while (0)
+#endif
+
 template <class Model, int MODE, bool RNG, bool FUSE>
 __global__ __launch_bounds__(kUgBlock) void smooth_ug_kernel(SmoothArgs a) {
     using TR = SmoothTraits<Model, MODE>;
@@ -506,51 +526,25 @@ __global__ __launch_bounds__(kUgBlock) void smooth_ug_kernel(SmoothArgs a) {
     const int t = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
 
+    UG_STAMP(0);
     // ---- prologue: the timestep's geometry (wave 0), then the table (everyone) ------------------------------
     if (wave == 0) {
+        // the model's QP assembly (trigonometry, closest points): one wave, every lane the same; lane 0 stores
         float xb[n], ub[m], q[n], Dinv[n], b0[n], J[NC][n], phi[NC];
 #pragma unroll
         for (int i = 0; i < n; ++i) xb[i] = (float)a.x_trj[(size_t)t * n + i];
 #pragma unroll
         for (int j = 0; j < m; ++j) ub[j] = (float)a.u_trj[(size_t)t * m + j];
         Model::template assemble<float>(a.p, xb, ub, q, Dinv, b0, J, phi);
-        // W, r0 by the expressions of irs_contact_qp_dual_exact_try
-        float JD[NC][n], Db[n], W[NC][NC], r0[NC];
-#pragma unroll
-        for (int k = 0; k < n; ++k) Db[k] = b0[k] * Dinv[k];
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-#pragma unroll
-            for (int k = 0; k < n; ++k) JD[i][k] = J[i][k] * Dinv[k];
-            float ri = phi[i];
-#pragma unroll
-            for (int k = 0; k < n; ++k) ri = ri - J[i][k] * Db[k];
-            r0[i] = ri;
-#pragma unroll
-            for (int j = 0; j <= i; ++j) {
-                float w = JD[i][0] * J[j][0];
-#pragma unroll
-                for (int k = 1; k < n; ++k) w = w + JD[i][k] * J[j][k];
-                W[i][j] = w;
-                W[j][i] = w;
-            }
-        }
         if (lane == 0) {
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
+                S.phi[i] = phi[i];
 #pragma unroll
-                for (int j = 0; j < NC; ++j) S.W[i][j] = W[i][j];
-                S.Wd[i] = W[i][i];
-                S.invw[i] = (float)kContactPgsOmega * irs_rcp_fast(W[i][i]);
-                S.r0[i] = r0[i];
-#pragma unroll
-                for (int k = 0; k < n; ++k) { S.JD[k][i] = JD[i][k]; S.Jc[i][k] = J[i][k]; }
-#pragma unroll
-                for (int j = 0; j < m; ++j)
-                    S.C[j][i] = JD[i][Model::act(j)] * Model::template stiffness<float>(a.p, j);
+                for (int k = 0; k < n; ++k) S.Jc[i][k] = J[i][k];
             }
 #pragma unroll
-            for (int k = 0; k < n; ++k) { S.Db0[k] = Db[k]; S.q[k] = q[k]; S.Dinv[k] = Dinv[k]; }
+            for (int k = 0; k < n; ++k) { S.Db0[k] = b0[k] * Dinv[k]; S.q[k] = q[k]; S.Dinv[k] = Dinv[k]; }
 #pragma unroll
             for (int j = 0; j < m; ++j) S.DK[j] = Dinv[Model::act(j)] * Model::template stiffness<float>(a.p, j);
         }
@@ -559,19 +553,52 @@ __global__ __launch_bounds__(kUgBlock) void smooth_ug_kernel(SmoothArgs a) {
         for (int q = tid; q < (1 << NC); q += BLOCK) hist[q] = 0u;
     }
     __syncthreads();
-    for (int e = tid; e < 2 * (1 << NC); e += BLOCK) ug_build_entry<Model>(S, (unsigned)(e >> 1), e & 1);
+    // what follows from it, one quantity per thread (the expressions of irs_contact_qp_dual_exact_try):
+    //   W = J D^-1 J' (entry (i,j) from the row pair (max, min): symmetric to the bit), r0 = phi - J D^-1 b,
+    //   J D^-1, C = J D^-1[:, act] K
+    if (tid < NC * NC) {
+        const int i = tid / NC, j = tid % NC, hi = i > j ? i : j, lo = i > j ? j : i;
+        float w = (S.Jc[hi][0] * S.Dinv[0]) * S.Jc[lo][0];
+#pragma unroll
+        for (int k = 1; k < n; ++k) w = w + (S.Jc[hi][k] * S.Dinv[k]) * S.Jc[lo][k];
+        S.W[i][j] = w;
+        if (i == j) {
+            S.Wd[i] = w;
+            S.invw[i] = (float)kContactPgsOmega * irs_rcp_fast(w);
+        }
+    } else if (tid < NC * NC + NC) {
+        const int i = tid - NC * NC;
+        float ri = S.phi[i];
+#pragma unroll
+        for (int k = 0; k < n; ++k) ri = ri - S.Jc[i][k] * S.Db0[k];
+        S.r0[i] = ri;
+    } else if (tid < 2 * NC * NC + NC) {
+        const int e = tid - (NC * NC + NC), k = e / NC, c = e % NC;
+        if (k < n) S.JD[k][c] = S.Jc[c][k] * S.Dinv[k];
+    } else if (tid < 2 * NC * NC + NC + m * NC) {
+        const int e = tid - (2 * NC * NC + NC), j = e / NC, c = e % NC;
+        S.C[j][c] = (S.Jc[c][Model::act(j)] * S.Dinv[Model::act(j)]) * Model::template stiffness<float>(a.p, j);
+    }
+    __syncthreads();
+    UG_STAMP(1);
+    if (!(a.diag & 4))
+        for (int e = tid; e < 2 * (1 << NC); e += BLOCK) ug_build_entry<Model>(S, (unsigned)(e >> 1), e & 1);
     __syncthreads();
 
-    // uniform operands of the sample loop -> scalar registers
+    UG_STAMP(2);
+    // the uniform operands of the sweeps, in VECTOR registers (one copy per lane).  Measured on gfx950
+    // (tools/microbench/valu_issue.hip): a v_fmac_f32 with ONE scalar-register operand costs a SIMD 6.4 cycles at two
+    // waves per SIMD (12.4 at one) against 2.9 with vector operands only -- scalar operands are read through a path
+    // the four SIMDs of a CU share -- so keeping W in SGPRs would more than halve the rate of the sweeps.
     UgUni<NC> U;
     {
         int q = 0;
 #pragma unroll
         for (int i = 0; i < NC; ++i)
 #pragma unroll
-            for (int j = i; j < NC; ++j) U.W[q++] = ug_uniform(S.W[i][j]);
+            for (int j = i; j < NC; ++j) U.W[q++] = S.W[i][j];
 #pragma unroll
-        for (int i = 0; i < NC; ++i) { U.invw[i] = ug_uniform(S.invw[i]); U.r0[i] = ug_uniform(S.r0[i]); }
+        for (int i = 0; i < NC; ++i) { U.invw[i] = S.invw[i]; U.r0[i] = S.r0[i]; }
     }
 
     float acc[PPI];
@@ -579,16 +606,35 @@ __global__ __launch_bounds__(kUgBlock) void smooth_ug_kernel(SmoothArgs a) {
     for (int i = 0; i < PPI; ++i) acc[i] = 0.f;
 
     const bool nominal_wave = blk == 0 && wave == NW - 1;
-    if (nominal_wave) {
-        ug_nominal<Model>(a, U, S, nomL, t, lane);
-    } else {
-        // 64-sample blocks are dealt round robin to the sampling waves of the timestep (all but the nominal one)
-        const int samplers = a.nblk * NW - 1;
-        const int me = blk == 0 ? wave : blk * NW - 1 + wave;
+    if (nominal_wave && !(a.diag & 2)) ug_nominal<Model>(a, U, S, nomL, t, lane);
+    if (nominal_wave) UG_STAMP(8);
+    if (!(a.diag & 8)) {
+        // 64-sample blocks are dealt round robin to the waves of the timestep: rounds 0 .. kUgNomRounds - 1 to all but
+        // the nominal wave (which is busy with the f64 step for about that long), later rounds to all of them
+        const int V = a.nblk * NW;
+        const int me = nominal_wave ? V - 1 : (blk == 0 ? wave : blk * NW - 1 + wave);
         const int nblocks = (a.N + 63) / 64;
+        int round = nominal_wave ? kUgNomRounds : 0;
+        auto block_of = [&](int k) { return k < kUgNomRounds ? k * (V - 1) + me : kUgNomRounds * (V - 1) + (k - kUgNomRounds) * V + me; };
         float* ring = ring_all + wave * (kUgRing * QE);
         int qhead = 0, qtail = 0;                           // wave-uniform
-        int bk = me;
+        int bk = block_of(round);
+        // the perturbations of the NEXT fresh trip are requested while this one computes: a trip is ~1.5 us of
+        // arithmetic, an HBM round trip ~0.5-1 us, and a SIMD holds two waves -- nothing else would hide it.  (No
+        // other vector-memory operation sits inside a trip, so the wait lands where the sample is consumed.)
+        float du_next[m];
+#pragma unroll
+        for (int j = 0; j < m; ++j) du_next[j] = 0.f;
+        auto request = [&](int block) {
+            if constexpr (!RNG) {
+                if (block < nblocks) {
+                    const int sidx = block * 64 + lane;
+                    const size_t row = (size_t)t * a.N + (sidx < a.N ? sidx : a.N - 1);
+                    load_row<m>(a.du + row * m, du_next);
+                }
+            }
+        };
+        request(bk);
         while (true) {
             const bool fresh = bk < nblocks;
             const int pending = qtail - qhead;
@@ -607,7 +653,7 @@ __global__ __launch_bounds__(kUgBlock) void smooth_ug_kernel(SmoothArgs a) {
                 for (int j = 0; j < m; ++j) du[j] = ring[slot * QE + j];
                 const unsigned wm = __float_as_uint(ring[slot * QE + m]);
                 const float tolv = ug_rhs<Model>(U, S, du, r);
-                ug_full<Model>(S, r, tolv, wm, lam);
+                ug_full<Model>(S, r, tolv, wm, lam, (a.diag & 128) ? 8 : ((a.diag & 256) ? 12 : 4 * NC));
                 qhead += take;
             } else {
                 const int sidx = bk * 64 + lane;
@@ -625,12 +671,14 @@ __global__ __launch_bounds__(kUgBlock) void smooth_ug_kernel(SmoothArgs a) {
                         }
                     }
                 } else {
-                    const size_t row = (size_t)t * a.N + (on ? sidx : a.N - 1);
-                    load_row<m>(a.du + row * m, du);
+#pragma unroll
+                    for (int j = 0; j < m; ++j) du[j] = du_next[j];
+                    request(block_of(round + 1));
                 }
                 const float tolv = ug_rhs<Model>(U, S, du, r);
                 unsigned mask = 0u;
-                fin_ = ug_try<Model>(U, S, r, tolv, lam, mask);
+                fin_ = ug_try<Model>(U, S, r, tolv, lam, mask, a.diag);
+                if (a.diag & 16) fin_ = true;
                 const bool hard = on && !fin_;
                 const unsigned long long bal = __ballot(hard);
                 if (hard) {
@@ -640,19 +688,19 @@ __global__ __launch_bounds__(kUgBlock) void smooth_ug_kernel(SmoothArgs a) {
                     ring[slot * QE + m] = __uint_as_float(mask);
                 }
                 qtail += __popcll(bal);
-                bk += samplers;
+                bk = block_of(++round);
             }
             const bool use = on && fin_;
             // a non-finite perturbation must not vanish in a clamp: poison the statistics (tested on the bit pattern)
             bool nonfinite = false;
 #pragma unroll
-            for (int j = 0; j < m; ++j) nonfinite = nonfinite || ((__float_as_uint(du[j]) & 0x7f800000u) == 0x7f800000u);
+            for (int j = 0; j < m; ++j) nonfinite = nonfinite || irs_nonfinite_bits(du[j]);
             if constexpr (TR::FIRST_B) {
                 unsigned I = 0u;
 #pragma unroll
-                for (int i = 0; i < NC; ++i) I |= (lam[i] * ug_uniform(S.Wd[i]) > (float)kContactActiveTol) ? (1u << i) : 0u;
+                for (int i = 0; i < NC; ++i) I |= (lam[i] * S.Wd[i] > (float)kContactActiveTol) ? (1u << i) : 0u;
                 if (use) __hip_atomic_fetch_add(&hist[I], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (on && nonfinite) acc[0] = ug_poison();
+                if (on && nonfinite) acc[0] = irs_poison();
             } else {
                 float zz[m];
 #pragma unroll
@@ -668,18 +716,21 @@ __global__ __launch_bounds__(kUgBlock) void smooth_ug_kernel(SmoothArgs a) {
                     for (int c = 0; c < NC; ++c) { acc[q] = fmaf(zz[i], lam[c], acc[q]); ++q; }
 #pragma unroll
                 for (int i = 0; i < m; ++i) { acc[q] += zz[i]; ++q; }
-                if (on && nonfinite) acc[0] = ug_poison();
+                if (on && nonfinite) acc[0] = irs_poison();
             }
         }
     }
 
+    UG_STAMP(3);
+    if (blk == 0 && wave == 1) UG_STAMP(9);
     // ---- workgroup statistics in the layout of `sums` (include/irs_hip.h) --------------------------------------
     if constexpr (TR::FIRST_B) {
         // sum over the samples of B(I_s) = sum over the occupied active sets of count(I) B(I), with
         //   Y = W_II^+ J[:, act] = -M_I J[:, act],   B[k][c] = [k = act c] - D^-1_k sum_i J[i][k] Y[i][c]
         // (irs_contact_qp_grad, WITH_A = false; the table's pivot rule is the derivative's, 1e-5)
         __syncthreads();
-        const float poison = acc[0];
+        unsigned poison_bits = __float_as_uint(acc[0]);
+        asm volatile("" : "+v"(poison_bits));
 #pragma unroll
         for (int i = 0; i < PPI; ++i) acc[i] = 0.f;
         for (int I = tid; I < (1 << NC); I += BLOCK) {
@@ -710,7 +761,7 @@ __global__ __launch_bounds__(kUgBlock) void smooth_ug_kernel(SmoothArgs a) {
                     acc[Model::perm(k) * m + c] += (float)cnt * Bkc;
                 }
         }
-        if ((__float_as_uint(poison) & 0x7f800000u) == 0x7f800000u) acc[0] = poison;
+        if ((poison_bits & 0x7f800000u) == 0x7f800000u) acc[0] = irs_poison();
         block_reduce_lds<P, NW>(acc, red);
     } else {
         block_reduce_lds<PI, NW>(acc, red);
@@ -749,7 +800,9 @@ __global__ __launch_bounds__(kUgBlock) void smooth_ug_kernel(SmoothArgs a) {
         __syncthreads();
         if (tid < P) red[tid] = out;
     }
+    UG_STAMP(4);
     smooth_finish<Model, MODE, FUSE, BLOCK, true>(a, red, red64, tot, fin, s_ticket, t, blk, tid, a.fnom + (size_t)t * n);
+    UG_STAMP(5);
 }
 
 template <class Model, int MODE>
@@ -765,6 +818,13 @@ void ug_launch_m(const SmoothArgs& a, bool rng, bool fuse, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef IRS_UG_STAMPS
+extern "C" int irs_debug_ug_stamps(unsigned long long* host_out, int n_wgs) {
+    if (n_wgs > kUgStampWgs) n_wgs = kUgStampWgs;
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ug_stamps), (size_t)n_wgs * kUgStampSlots * sizeof(unsigned long long));
+}
+#endif
 
 bool irs_smooth_ug_supported(int model, int mode) {
     const char* e = getenv("IRS_UG");

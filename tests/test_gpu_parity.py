@@ -1683,14 +1683,19 @@ def test_contact_model_sums_layout_vs_oracle(amd):
     A3, B3, c3, i3 = dm.smooth_finalize(SMOOTH_ZERO_ORDER_B, N, xd, ud, s2,
                                         workspace=dm._workspace(SMOOTH_ZERO_ORDER_B, T, N, xd.device))
     assert int(i3.abs().sum().item()) == 0
-    assert torch.equal(B3, B2) and torch.equal(c3, c2) and torch.equal(A3, A2)
+    # (the f64 nominal step in the workspace comes from the sample pass's cooperative solve, csrc/smooth_ug.hip; the
+    # stand-alone solve evaluates the model's step itself: same KKT point, another order of f64 operations)
+    assert torch.equal(A3, A2)
+    np.testing.assert_allclose(B3.cpu().numpy(), B2.cpu().numpy(), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(c3.cpu().numpy(), c2.cpu().numpy(), rtol=0, atol=1e-12)
     # a single-workgroup accumulate (small N) leaves them too
     du_s = dev.to_dev(du[:, :200].copy(), dev.F32)
     s4 = dm.smooth_accumulate(SMOOTH_ZERO_ORDER_B, xd, ud, None, du_s)
     r4 = dm.smooth_finalize(SMOOTH_ZERO_ORDER_B, 200, xd, ud, s4)
     r5 = dm.smooth_finalize(SMOOTH_ZERO_ORDER_B, 200, xd, ud, s4,
                             workspace=dm._workspace(SMOOTH_ZERO_ORDER_B, T, 200, xd.device))
-    assert torch.equal(r4[1], r5[1]) and torch.equal(r4[2], r5[2])
+    np.testing.assert_allclose(r4[1].cpu().numpy(), r5[1].cpu().numpy(), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(r4[2].cpu().numpy(), r5[2].cpu().numpy(), rtol=0, atol=1e-12)
     f2 = dm.smooth(SMOOTH_ZERO_ORDER_B, xd, ud, None, dev.to_dev(du, dev.F32))
     np.testing.assert_allclose(f2["Bt"].cpu().numpy(), B2.cpu().numpy(), rtol=0, atol=2e-5)
     np.testing.assert_allclose(f2["ct"].cpu().numpy(), c2.cpu().numpy(), rtol=0, atol=2e-5)
