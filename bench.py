@@ -25,6 +25,7 @@ Sub-reports of the default single-GPU run (all in the same JSON line):
   "sweep_N"             the metric's workload at N = 1e3 and 1e5 (north_star's N points)
   "first_order"         the reference's planar-hand gradient mode (planar_hand_setup.py:28)
   "pgs_contact_solver"  the opt-in approximate step-QP solver (50 projected sweeps + polish)
+  "general_kernel"      the metric's workload through the general contact kernel (IRS_UG=0), for the record
   "pendulum"            BASELINE configs[1]: zero-order AB, T=30, N=1e4 (the HBM-bound case)
   "quadrotor"           BASELINE configs[2]: first-order, T=50, N=1e4 + on-device Riccati descent
   "box_pivoting"        BASELINE configs[4] at its per-GPU size (T=80, N=5e4/8): iRS-LQR (zero-order-B,
@@ -51,8 +52,10 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 VALU_F32_PEAK_TFLOPS = 157.3  # peak FP32 (vector), same guide
-SIMDS, CLOCK_GHZ, ISSUE_CYCLES = 1024, 2.4, 4     # 256 CUs x 4 SIMDs; max clock; cycles one wave's VALU
-#                                                   instruction holds its SIMD's issue (same guide, constants table)
+# 256 CUs x 4 SIMDs; max clock.  A wave64 VALU instruction EXECUTES in 2 cycles on the SIMD-32 (same guide, :54,473):
+# that is the chip's capacity; one wave ALONE on a SIMD sustains one instruction per 4 cycles (:489), the ceiling of a
+# kernel that holds one wave per SIMD (the general contact kernel; the uniform-geometry kernel holds two).
+SIMDS, CLOCK_GHZ, ISSUE_CYCLES, ISSUE_CYCLES_ONE_WAVE = 1024, 2.4, 2, 4
 
 # Algorithmic flops of ONE u-perturbed contact step of the planar hand inside the sample pass
 # (csrc/contact_models.hpp).  In the u-only modes the state is not perturbed, so the
@@ -66,6 +69,14 @@ SIMDS, CLOCK_GHZ, ISSUE_CYCLES = 1024, 2.4, 4     # 256 CUs x 4 SIMDs; max clock
 #   zero-order-B statistics (Gram 10 + cross 28 FMAs)                              76
 #   first-order extras: 4 right-hand sides through the factor, J'Y, B, sum       1208
 _F = dict(r=64, sweep=152, ldl_solve=316, slack=128, primal=126, gram=76, first=1208, polish=470)
+# ... and of the uniform-geometry kernel (csrc/smooth_ug.hip), what EVERY sample does:
+#   r = r0 + C du                                                        8 x 4 x 2 =   64
+#   6 projected sweeps, W in registers (per row: fma, max, sub, 8 fma)     6 x 8 x 20 =  960
+#   4 primal-dual active-set iterations (table row: 8 mul + 64 fma)         4 x 136 =  544
+#   statistics: Gram 10 fma + du lam' 32 fma + sum du 4                               88
+# (the parked ~10 % of the samples' dual active-set steps are NOT counted: a lower bound)
+UG_SWEEPS, UG_PDAS = 6, 4
+_FUG = dict(r=64, sweep=160, pdas=136, stats=88, first=8)
 
 
 def contact_flops_per_sample(solver, pgs_iters, first_order):
@@ -74,6 +85,11 @@ def contact_flops_per_sample(solver, pgs_iters, first_order):
     counted -- 32 warm-up sweeps, one factorisation + solve, the slacks -- so the figure is a LOWER bound of
     the algorithmic flops and roofline.frac a lower bound with it."""
     tail = _F["primal"] + (_F["first"] if first_order else _F["gram"])
+    if solver == "ug":
+        f = _FUG["r"] + UG_SWEEPS * _FUG["sweep"] + UG_PDAS * _FUG["pdas"] + (_FUG["first"] if first_order else _FUG["stats"])
+        return f, "64 (r) + %d*160 (sweeps) + %d*136 (active-set iterations by table row) + %s; parked samples' " \
+                  "dual active-set steps NOT counted (lower bound)" % (UG_SWEEPS, UG_PDAS,
+                                                                        "8 (active-set key)" if first_order else "88 (statistics)")
     if solver == "exact":
         f = _F["r"] + 32 * _F["sweep"] + _F["ldl_solve"] + _F["slack"] + tail
         return f, "64 (r) + 32*152 (warm-up sweeps) + 316 (masked LDL' + solve) + 128 (slacks) + 126 (primal) + %s; " \
@@ -142,14 +158,17 @@ class Workload:
                 # step is differentiated through its active constraints inside the sample pass
                 self.mode, self.mode_name = _lib.SMOOTH_FIRST_ORDER, "FIRST_ORDER"
             model = "PlanarHandExactModel" if contact_solver == "exact" else "PlanarHandModel"
+            # the exact 8-row model in a u-only mode runs the uniform-geometry kernel unless IRS_UG=0 forces the general one
+            self.uniform_geometry = contact_solver == "exact" and os.environ.get("IRS_UG", "1") != "0"
             self.label = "planar_hand quasi-dynamic contact, %s smoothing, step QP %s" % (
                 "first-order (per-sample active-set derivative)" if first else "zero-order-B",
                 "solved exactly (dual active-set method)" if contact_solver == "exact"
                 else "by %d projected sweeps + polish (opt-in)" % int(sd.pgs_iters))
             if not first and contact_solver == "exact":
                 self.label += " -- the metric's config"
-            self.kernel = "smooth_kernel<%s, %s>" % (model, self.mode_name)
-            self.flops_per_sample, self.flops_formula = contact_flops_per_sample(contact_solver, int(sd.pgs_iters), first)
+            self.kernel = "%s<%s, %s>" % ("smooth_ug_kernel" if self.uniform_geometry else "smooth_kernel", model, self.mode_name)
+            self.flops_per_sample, self.flops_formula = contact_flops_per_sample(
+                "ug" if self.uniform_geometry else contact_solver, int(sd.pgs_iters), first)
         elif name == "box_pivoting":
             # examples/box_pivoting/run_box_pivoting.py:20-131 (BASELINE configs[4]: T = 80)
             self.T = T or 80
@@ -345,9 +364,15 @@ def roofline(w, N, k_ms, nm):
             traffic = (2.0 * pmc["FETCH_SIZE_raw_avg"] + pmc.get("WRITE_SIZE_raw_avg", 0.0)) * 1024.0
         if "SQ_INSTS_VALU_raw_avg" in pmc and pmc.get("kernel_avg_ns"):
             # share of the chip's VALU issue slots the launch used, all from the profile (its own kernel time)
-            issue = {"frac": pmc["SQ_INSTS_VALU_raw_avg"] * ISSUE_CYCLES / SIMDS / CLOCK_GHZ / pmc["kernel_avg_ns"],
-                     "formula": "SQ_INSTS_VALU x %d cycles / %d SIMDs / %.1f GHz / kernel_avg_ns (both from the profile)"
+            base = pmc["SQ_INSTS_VALU_raw_avg"] / SIMDS / CLOCK_GHZ / pmc["kernel_avg_ns"]
+            issue = {"frac": base * ISSUE_CYCLES,
+                     "formula": "SQ_INSTS_VALU x %d cycles (a wave64 VALU instruction on the SIMD-32) / %d SIMDs / %.1f GHz / "
+                                "kernel_avg_ns (both from the profile): the share of the CHIP's VALU capacity"
                                 % (ISSUE_CYCLES, SIMDS, CLOCK_GHZ),
+                     "frac_of_one_wave_per_simd_ceiling": base * ISSUE_CYCLES_ONE_WAVE,
+                     "one_wave_note": "x %d cycles: what ONE wave per SIMD can issue at most -- the ceiling of the general "
+                                      "contact kernel (388 registers); the uniform-geometry kernel holds two waves per SIMD"
+                                      % ISSUE_CYCLES_ONE_WAVE,
                      "SQ_INSTS_VALU": pmc["SQ_INSTS_VALU_raw_avg"], "kernel_avg_ns": pmc["kernel_avg_ns"],
                      "valu_insts_per_sample": pmc["SQ_INSTS_VALU_raw_avg"] * 64.0 / (N * w.T)}
     r = {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
@@ -791,10 +816,17 @@ def main():
         "timed_region_s": el,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "parity": ("partial: the contact STEP and its derivative are pinned by the simulator data the reference ships "
-                   "(box_pushing) and the optimiser around them by the reference's result files; the planar-hand / "
-                   "box-pivoting geometry and parameters (mass, friction) are NOT pinned -- the simulator's model files "
-                   "are absent (DESIGN.md 3)") if contact else "pinned by reference-run fixtures and result files",
+        "parity": (("planar hand PINNED by the reference's own result files: the first entry of examples/planar_hand/"
+                    "analysis/planar_hand_spin_{exact,zero_order_B,first_order}.csv (the script's initial 30-step "
+                    "simulator rollout) is reproduced to 2e-10 by the oracle and by the device functor (geometry, "
+                    "stiffness, mass; friction identified only as >= 0.5: the grasp sticks); contact step + derivative "
+                    "pinned by the simulator data of box_pushing; later entries of those files depend on Gurobi's "
+                    "multipliers and the simulator's truncated least squares and are not reproducible (DESIGN.md 3)")
+                   if w.name == "planar_hand" else
+                   "partial: contact step and derivative pinned on box_pushing (simulator data), optimiser by the "
+                   "reference's result files; the box-pivoting geometry is NOT pinned (its result files' first entry is "
+                   "1.1 % off for every mass / friction: DESIGN.md 3)") if contact
+        else "pinned by reference-run fixtures and result files",
         "config": {"workload": w.label, "T": T, "N_per_gpu": N, "N_total": N * world, "mode": w.mode_name,
                    "contact_solver": w.contact_solver if contact else None,
                    "samples": "supplied, resident in HBM (f32)",
@@ -839,6 +871,16 @@ def main():
         # the opt-in approximate step-QP solver
         out["pgs_contact_solver"] = sub_report(Workload("planar_hand", args.T, None, contact_solver="pgs"), N,
                                                max(20, args.steps // 4))
+        if w.uniform_geometry:
+            # the same workload through the GENERAL contact kernel (csrc/smooth.hip: per-lane geometry and LDL', parked
+            # samples; rounds 1-2's kernel), for the record
+            os.environ["IRS_UG"] = "0"
+            try:
+                out["general_kernel"] = sub_report(Workload("planar_hand", args.T, None), N, max(20, args.steps // 4))
+                out["general_kernel"]["note"] = ("IRS_UG=0: smooth_kernel<PlanarHandExactModel, ZERO_ORDER_B>, one wave per "
+                                                 "SIMD; the default since round 3 is smooth_ug_kernel (uniform geometry)")
+            finally:
+                del os.environ["IRS_UG"]
     if secondary and w.name != "pendulum":
         out["pendulum"] = sub_report(Workload("pendulum"), 10000, max(200, 5 * args.steps), 1000, sweep_N=(1000, 100000))
     if secondary and w.name != "quadrotor":

@@ -56,3 +56,14 @@ def test_adopted_profile_is_committed_and_stamped():
     assert "single-workload" in e["kernel_avg_source"] and 5e4 < e["kernel_avg_ns"] < 2e5
     slots = e["SQ_INSTS_VALU_raw_avg"] * 4 / 1024 / 2.4 / e["kernel_avg_ns"]
     assert 0.2 < slots < 1.0, slots
+
+
+def test_flop_model_of_the_uniform_geometry_kernel():
+    """smooth_ug_kernel (csrc/smooth_ug.hip): what every sample does -- r, 6 sweeps, 4 table-row iterations, the
+    statistics; the parked samples' dual active-set steps are not counted (a lower bound, said so)."""
+    import bench
+    f, s = bench.contact_flops_per_sample("ug", 50, False)
+    assert f == 64 + 6 * 160 + 4 * 136 + 88 and "lower bound" in s
+    f1, _ = bench.contact_flops_per_sample("ug", 50, True)
+    assert f1 == f - 88 + 8
+    assert bench.ISSUE_CYCLES == 2 and bench.ISSUE_CYCLES_ONE_WAVE == 4

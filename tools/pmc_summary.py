@@ -20,7 +20,7 @@ def short(name):
     looks up the supplied-samples, fused variants; the device-RNG variants are the ones of the iLQR loop).
     T and N are those of the profiled command (tools/profile_round.sh), not read from the trace."""
     import re
-    m = re.search(r"smooth_kernel<(?:\(anonymous namespace\)::)?(\w+)[,;] (\d)[,;] (true|false)[,;] (true|false)", name)
+    m = re.search(r"smooth(?:_ug)?_kernel<(?:\(anonymous namespace\)::)?(\w+)[,;] (\d)[,;] (true|false)[,;] (true|false)", name)
     if m:
         model, mode, rng, fuse = m.group(1), int(m.group(2)), m.group(3) == "true", m.group(4) == "true"
         tag = {0: "zero", 1: "first", 2: "zeroB"}[mode] + ("_rng" if rng else "") + ("" if fuse else "_unfused")
@@ -53,7 +53,7 @@ if f:
         if k:
             res[k]["kernel_avg_ns"] = float(r["AverageNs"])
             res[k]["kernel_calls"] = int(r["Calls"])
-            if "smooth_kernel" in r["Name"]:
+            if "smooth_kernel" in r["Name"] or "smooth_ug_kernel" in r["Name"]:
                 res[k]["smooth_kernel_avg_ns"] = float(r["AverageNs"])
 for d in sorted(glob.glob("%s/pmc_*" % out_dir)):
     if not os.path.isdir(d):
@@ -74,7 +74,7 @@ for d in sorted(glob.glob("%s/pmc_*" % out_dir)):
 for f in sorted(glob.glob("%s/stats_*/*/*kernel_stats.csv" % out_dir)):
     for r in csv.DictReader(open(f)):
         k = short(r["Name"])
-        if k and "smooth_kernel" in r["Name"] and "_rng" not in k:
+        if k and ("smooth_kernel" in r["Name"] or "smooth_ug_kernel" in r["Name"]) and "_rng" not in k:
             res[k]["kernel_avg_ns"] = float(r["AverageNs"])
             res[k]["smooth_kernel_avg_ns"] = float(r["AverageNs"])
             res[k]["kernel_calls"] = int(r["Calls"])
