@@ -754,6 +754,68 @@ def main():
         assert info == 0, "smoothing solve reported a non-SPD Gram matrix or a non-finite statistic"
         return el, el_it, k_ms, (n, m), loop
 
+    def public_api(w_, N_, k_iters, episodes=3):
+        """iLQR iterations / s through the PUBLIC classes a user of the reference switches to: `solver.iterate(k)` of
+        IrsLqrZeroOrder / IrsLqrFirstOrder (one irs_iterate library call: csrc/iterate.hip) or IrsLqrQuasistatic (all
+        descents enqueued without a host synchronisation, one read-back), quiet, samples drawn on the device
+        (GaussianSmoothing / params.device_rng_seed: the extensions that keep the perturbations off the host; the
+        reference's host closures cost 20 ms of NumPy draws per iteration at this size).  Timed: iterate() alone,
+        k + 1 descents per call, a fresh solver per episode (its construction -- initial rollout -- is set-up)."""
+        import irs_mpc_amd as amd
+        m_ = w_.system.dim_u
+
+        def make():
+            if w_.bounds is None:
+                p = amd.IrsLqrParameters()
+                p.Q, p.Qd, p.R, p.x0, p.xd_trj, p.u_trj_initial = w_.Q, w_.Qd, w_.R, w_.x0, w_.xd, w_.u_trj
+                smp = amd.GaussianSmoothing(np.full(w_.system.dim_x, w_.std_x), np.full(m_, w_.std_u), N_, power=0.5, seed=11)
+                cls = amd.IrsLqrFirstOrder if w_.mode_name == "FIRST_ORDER" else amd.IrsLqrZeroOrder
+                sol = cls(w_.system, p, smp)
+            else:
+                sd = w_.system
+                p = amd.IrsLqrQuasistaticParameters()
+                names = sd.models_unactuated + sd.models_actuated
+                p.Q_dict = {k_: np.diag(w_.Q)[sd.position_indices[k_]] for k_ in names}
+                p.Qd_dict = {k_: np.diag(w_.Qd)[sd.position_indices[k_]] for k_ in names}
+                p.R_dict, i0 = {}, 0
+                for k_ in sd.models_actuated:
+                    nk = len(sd.position_indices[k_])
+                    p.R_dict[k_] = np.diag(w_.R)[i0:i0 + nk]
+                    i0 += nk
+                p.x0, p.x_trj_d, p.u_trj_0, p.T = w_.x0, w_.xd, w_.u_trj, w_.T
+                kind, wd = w_.bounds
+                box = np.array([-np.ones(m_) * wd, np.ones(m_) * wd])
+                if kind == "abs":
+                    p.u_bounds_abs = box
+                else:
+                    p.u_bounds_rel = box
+                p.sampling = lambda u_initial, it: np.full(m_, w_.std_schedule(it))
+                p.std_u_initial = np.full(m_, w_.std_u)
+                p.num_samples = N_
+                p.gradient_mode = "first_order" if w_.mode_name == "FIRST_ORDER" else "zero_order_B"
+                p.publish_every_iteration = False
+                p.device_rng_seed = 11
+                sol = amd.IrsLqrQuasistatic(sd, p)
+            sol.verbose = False
+            return sol
+
+        make().iterate(min(2, k_iters))            # warm-up (allocations, lazy initialisation)
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(episodes):
+            sol = make()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sol.iterate(k_iters)
+            dt = time.perf_counter() - t0          # iterate() returns host arrays: the read-back is inside
+            best = dt if best is None or dt < best else best
+        hist = sol.cost_lst if hasattr(sol, "cost_lst") else sol.cost_all_list
+        return {"iters_per_s": (k_iters + 1) / best, "ms_per_iter": 1e3 * best / (k_iters + 1),
+                "call": "%s.iterate(%d): %d descents per call, best of %d calls" % (type(sol).__name__, k_iters, k_iters + 1, episodes),
+                "cost_first": float(hist[0]), "cost_last": float(hist[-1]),
+                "path": ("one irs_iterate library call (descents enqueued back to back, one read-back)"
+                         if w_.bounds is None else "host loop without device synchronisation, one read-back")}
+
     def sub_report(w_, N_, steps_, warm_=None, sweep_N=(), **kw):
         e, ei, km, nm_, lp = run(w_, N_, steps_, warm_ if warm_ is not None else max(1, steps_ // 10), **kw)
         r = {"config": {"workload": w_.label, "T": w_.T, "N_per_gpu": N_, "mode": w_.mode_name},
@@ -763,6 +825,15 @@ def main():
              "ilqr_first_iter_per_s": steps_ / ei, "roofline": roofline(w_, N_, km, nm_)}
         if lp:
             r["ilqr_loop"] = lp
+        if world == 1 and not unfused:
+            try:
+                # (quadrotor: the script's own 3 iterations, examples/quadrotor/quadrotor_first_order.py:57 -- without a line
+                # search the optimisation breaks down a few iterations later, at this horizon, in the reference too)
+                api = public_api(w_, N_, (kw.get("loop_iters", 20) - 1) if w_.bounds is not None
+                                 else (3 if w_.name == "quadrotor" else 99))
+                r["ilqr_iters_per_s_public_api"], r["public_api"] = api["iters_per_s"], api
+            except Exception as e:      # noqa: BLE001 -- an optimisation that breaks down is reported, not fatal
+                r["ilqr_iters_per_s_public_api"], r["public_api"] = None, {"error": repr(e)[:200]}
         if sweep_N:                                   # north_star's other N points for this workload
             r["sweep_N"] = {}
             for Ns in sweep_N:
@@ -843,6 +914,12 @@ def main():
                       if contact else "smoothing launch + Riccati + closed-loop rollout + cost (bounds inactive)"),
         "roofline": roofline(w, N, k_mean, nm),
     }
+    if world == 1 and not unfused:
+        try:
+            api = public_api(w, N, 19 if contact else (3 if w.name == "quadrotor" else 99))
+            out["ilqr_iters_per_s_public_api"], out["public_api"] = api["iters_per_s"], api
+        except Exception as e:      # noqa: BLE001
+            out["ilqr_iters_per_s_public_api"], out["public_api"] = None, {"error": repr(e)[:200]}
     if unfused:
         out["config"]["step"] = ("accumulate launch + all-reduce + solve launch, replayed as one HIP graph"
                                  if step_info.get("graph") else

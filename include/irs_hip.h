@@ -436,6 +436,69 @@ typedef struct irs_descent_call {
 /* irs_tvlqr_descent, by struct.                                                    */
 int irs_descent_run(const irs_descent_call *call, void *stream);
 
+/* ---- IrsLqr.iterate as one call (csrc/iterate.hip) ---------------------------------------------------------
+ * irs_lqr/irs_lqr.py:188-218: `n_descents` descents (iterate(k) performs k + 1), each = get_TV_matrices (device-drawn
+ * samples: irs_smooth_rng; or IRS_ITERATE_EXACT: irs_exact_linearize) -> irs_tvlqr_descent -> with box bounds:
+ * irs_tvlqr_plan_within_bounds and, behind its device-side flag, irs_tvlqr_box_descent_if -- all enqueued back to back
+ * on `stream`, no host synchronisation between phases or iterations.  Descent i linearises around the trajectory
+ * descent i-1 wrote into x_hist / u_hist (descent 0: x_trj0 / u_trj0); the caller reads the histories back once.
+ * std_x (n_descents, n) / std_u (n_descents, m): HOST, the sampling schedule evaluated by the caller (e.g.
+ * sigma / iter^p, examples/pendulum/pendulum_zero_order.py:38-43); Philox iteration counter of descent i = iter0 + i.
+ * info_hist (n_descents, 8) DEV int32 per descent: [0] Riccati info (t+1 of a non-PD Hessian), [1] number of
+ * timesteps whose smoothing solve failed, [2] 1 = some tail's unconstrained plan left the box (the bounded descent
+ * ran), [3..5] its info (irs_tvlqr_box_descent), [6] 1 = it was needed but the horizon does not fit its kernel.
+ * scratch: DEV, >= irs_iterate_scratch_bytes(model, mode, T, N).  timing (optional, HOST out): per-phase device
+ * time summed over the descents -- timing mode synchronises after every descent; NULL = fully asynchronous.   */
+#define IRS_ITERATE_EXACT 3
+typedef struct irs_iterate_call {
+    int model, n_params;
+    double params[12];
+    int mode, T, N, n_descents;
+    const double *std_x, *std_u;               /* HOST (n_descents, n) / (n_descents, m); std_x NULL in u-only modes */
+    uint64_t seed;
+    uint32_t iter0;
+    const double *Q, *Qd, *R, *xd_trj;         /* DEV */
+    double alpha_R;
+    const double *xlo, *xhi, *ulo, *uhi;       /* DEV (n) / (m), all four or none */
+    double qp_rho, qp_relax, qp_eps;           /* bounded descent (ADMM); <= 0: defaults 10, 1.6, 1e-8 */
+    int qp_max_iter;                           /* <= 0: 5000 */
+    const double *x_trj0, *u_trj0;             /* DEV (T+1, n), (T, m): the nominal trajectory of descent 0 */
+    double *x_hist, *u_hist, *cost_hist;       /* DEV out (n_descents, T+1, n), (n_descents, T, m), (n_descents) */
+    int *info_hist;                            /* DEV out (n_descents, 8) */
+    void *scratch;
+    size_t scratch_bytes;
+} irs_iterate_call;
+
+/* what SURVEY 8(b) calls irs_get_timing: filled by irs_iterate when asked for */
+typedef struct irs_timing {
+    double linearise_ms, descent_ms, bounds_ms;   /* device time per phase, summed over the descents */
+    int descents;
+    double sample_steps;                          /* N x T x descents one-step evaluations */
+    double sample_bytes;                          /* the f32 perturbations those would stream if supplied */
+} irs_timing;
+
+size_t irs_iterate_scratch_bytes(int model, int mode, int T, int N);
+int irs_iterate(const irs_iterate_call *call, irs_timing *timing, void *stream);
+
+/* *flag (DEV int32) = 1 iff the unconstrained plan of SOME tail QP (start t, realised state x_new[t], policy K, k rolled
+ * out on the linear model) violates the box xlo <= x <= xhi (n), ulo <= u <= uhi (m): only then do the bounded QPs
+ * of irs_lqr/tv_lqr.py:112-123 differ from the Riccati descent.  n <= 32, m <= 16.                              */
+int irs_tvlqr_plan_within_bounds(int n, int m, int T, const double *At, const double *Bt, const double *ct,
+                                 const double *K, const double *k, const double *x_new,
+                                 const double *xlo, const double *xhi, const double *ulo, const double *uhi,
+                                 int *flag, void *stream);
+
+/* irs_tvlqr_box_descent that (a) also returns evaluate_cost of its result (cost, may be NULL) and (b) returns at
+ * once, writing nothing, when *run_flag (DEV int32, may be NULL = always run) is 0.                            */
+int irs_tvlqr_box_descent_if(int model, const double *params, int n_params, int T,
+                             const double *At, const double *Bt, const double *ct,
+                             const double *Q, const double *Qd, const double *R, double alpha_R,
+                             const double *xd_trj, const double *x0,
+                             const double *xlo, const double *xhi, const double *ulo, const double *uhi,
+                             double rho, double relax, int max_iter, double eps,
+                             double *x_new, double *u_new, double *cost, int *info, const int *run_flag,
+                             void *stream);
+
 /* ---- the multi-GPU smoothing step inside the library (csrc/collective.hip) ------------------------------
  * One process per GPU; samples sharded over the ranks; per step: sample pass -> ONE all-reduce of the
  * (T,P) f64 statistics (RCCL over xGMI) -> solve (every rank, redundantly).  Replaces the reference's ZeroMQ

@@ -92,6 +92,33 @@ class DescentCall(ctypes.Structure):
                 ("cost", c_void_p), ("info", c_void_p)]
 
 
+class IterateCall(ctypes.Structure):
+    """irs_iterate_call (include/irs_hip.h)."""
+    _fields_ = [("model", c_int), ("n_params", c_int), ("params", c_double * 12),
+                ("mode", c_int), ("T", c_int), ("N", c_int), ("n_descents", c_int),
+                ("std_x", c_void_p), ("std_u", c_void_p), ("seed", c_uint64), ("iter0", c_uint32),
+                ("Q", c_void_p), ("Qd", c_void_p), ("R", c_void_p), ("xd_trj", c_void_p), ("alpha_R", c_double),
+                ("xlo", c_void_p), ("xhi", c_void_p), ("ulo", c_void_p), ("uhi", c_void_p),
+                ("qp_rho", c_double), ("qp_relax", c_double), ("qp_eps", c_double), ("qp_max_iter", c_int),
+                ("x_trj0", c_void_p), ("u_trj0", c_void_p),
+                ("x_hist", c_void_p), ("u_hist", c_void_p), ("cost_hist", c_void_p), ("info_hist", c_void_p),
+                ("scratch", c_void_p), ("scratch_bytes", c_size_t)]
+
+
+class Timing(ctypes.Structure):
+    """irs_timing (include/irs_hip.h)."""
+    _fields_ = [("linearise_ms", c_double), ("descent_ms", c_double), ("bounds_ms", c_double), ("descents", c_int),
+                ("sample_steps", c_double), ("sample_bytes", c_double)]
+
+
+ITERATE_EXACT = 3
+SIGNATURES["irs_iterate_scratch_bytes"] = (c_size_t, [c_int, c_int, c_int, c_int])
+SIGNATURES["irs_iterate"] = (c_int, [POINTER(IterateCall), POINTER(Timing), c_void_p])
+SIGNATURES["irs_tvlqr_plan_within_bounds"] = (c_int, [c_int, c_int, c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp,
+                                                      _dp, c_void_p])
+SIGNATURES["irs_tvlqr_box_descent_if"] = (c_int, [c_int, POINTER(c_double), c_int, c_int, _dp, _dp, _dp, _dp, _dp, _dp,
+                                                  c_double, _dp, _dp, _dp, _dp, _dp, _dp, c_double, c_double, c_int,
+                                                  c_double, _dp, _dp, _dp, _dp, _dp, c_void_p])
 SIGNATURES["irs_cem_rollout_costs"] = (c_int, [c_int, POINTER(c_double), c_int, c_int, c_int, _dp, _dp, _dp, _dp,
                                                _dp, _dp, c_void_p])
 SIGNATURES["irs_cem_rollout_costs_quasistatic"] = (c_int, [c_int, POINTER(c_double), c_int, c_int, c_int, _dp, _dp, _dp,

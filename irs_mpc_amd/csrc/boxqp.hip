@@ -52,6 +52,7 @@ struct BoxLayout {
 
 template <class Model, bool DU>
 __global__ __launch_bounds__(64) void box_descent_kernel(BoxArgs a) {
+    if (a.run_flag != nullptr && *a.run_flag == 0) return;          // uniform
     constexpr int NR = Model::NX, M = Model::NU;      // real state / control sizes
     constexpr int N = NR + (DU ? M : 0);              // size of the QP's state (z = [x; u_prev] if DU)
     constexpr double INF = __builtin_huge_val();
@@ -448,11 +449,15 @@ int launch_box(const BoxArgs& a, hipStream_t st) {
         return IRS_ERR_UNSUPPORTED;
     }
     auto kern = box_descent_kernel<Model, DU>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) {
-        irs_set_error("irs_tvlqr_box_descent: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        return IRS_ERR_HIP;
+    static size_t granted = 0;           // per instantiation: the attribute call is a driver round trip (fused iterate)
+    if (bytes > granted) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) {
+            irs_set_error("irs_tvlqr_box_descent: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return IRS_ERR_HIP;
+        }
+        granted = bytes;
     }
     hipLaunchKernelGGL(kern, dim3(1), dim3(64), bytes, st, a);
     return IRS_OK;
@@ -490,15 +495,30 @@ int irs_tvlqr_box_descent(int model, const double* params, int n_params, int T, 
     IRS_CHECK_ARG(T > 0 && At && Bt && ct && Q && Qd && R && xd_trj && x0 && xlo && xhi && ulo && uhi &&
                   x_new && u_new && info, "bad argument");
     IRS_CHECK_ARG(rho > 0.0 && relax > 0.0 && relax < 2.0 && max_iter > 0 && eps > 0.0, "bad ADMM parameter");
+    return irs_tvlqr_box_descent_if(model, params, n_params, T, At, Bt, ct, Q, Qd, R, alpha_R, xd_trj, x0, xlo, xhi, ulo,
+                                    uhi, rho, relax, max_iter, eps, x_new, u_new, nullptr, info, nullptr, stream);
+}
+
+int irs_tvlqr_box_descent_if(int model, const double* params, int n_params, int T, const double* At,
+                             const double* Bt, const double* ct, const double* Q, const double* Qd,
+                             const double* R, double alpha_R, const double* xd_trj, const double* x0,
+                             const double* xlo, const double* xhi, const double* ulo, const double* uhi,
+                             double rho, double relax, int max_iter, double eps, double* x_new,
+                             double* u_new, double* cost, int* info, const int* run_flag, void* stream) {
+    IRS_CHECK_ARG(T > 0 && At && Bt && ct && Q && Qd && R && xd_trj && x0 && xlo && xhi && ulo && uhi &&
+                  x_new && u_new && info, "bad argument");
+    IRS_CHECK_ARG(rho > 0.0 && relax > 0.0 && relax < 2.0 && max_iter > 0 && eps > 0.0, "bad ADMM parameter");
     BoxArgs a;
     a.act_io = nullptr;
     a.single_tail = 0;
+    a.run_flag = nullptr;
+    a.run_flag = run_flag;
     int rc = irs_load_params(model, params, n_params, &a.p);
     if (rc != IRS_OK) return rc;
     a.At = At; a.Bt = Bt; a.ct = ct; a.Q = Q; a.Qd = Qd; a.R = R; a.xd = xd_trj; a.x0 = x0;
     a.xlo = xlo; a.xhi = xhi; a.ulo = ulo; a.uhi = uhi; a.dlo = nullptr; a.dhi = nullptr;
     a.sx = 0; a.su = 0; a.sd = 0;
-    a.x_new = x_new; a.u_new = u_new; a.cost = nullptr; a.info = info;
+    a.x_new = x_new; a.u_new = u_new; a.cost = cost; a.info = info;
     a.alpha = alpha_R; a.rho = rho; a.relax = relax; a.eps = eps; a.T = T; a.max_iter = max_iter;
     hipStream_t st = static_cast<hipStream_t>(stream);
     IRS_DISPATCH_MODEL(model, { rc = launch_box<Model, false>(a, st); });
@@ -555,6 +575,7 @@ int irs_quasistatic_box_descent_wsx(int model, const double* params, int n_param
     BoxArgs a;
     a.act_io = act_io;
     a.single_tail = 0;
+    a.run_flag = nullptr;
     int rc = irs_load_params(model, params, n_params, &a.p);
     if (rc != IRS_OK) return rc;
     int n, m, np;
@@ -617,6 +638,7 @@ int irs_tvlqr_box_solve(int model, const double* params, int n_params, int T, co
     BoxArgs a;
     a.act_io = nullptr;
     a.single_tail = 1;
+    a.run_flag = nullptr;
     int rc = irs_load_params(model, params, n_params, &a.p);
     if (rc != IRS_OK) return rc;
     int n, m, np;

@@ -24,6 +24,10 @@ struct BoxArgs {
     // ADMM kernel only: 1 = solve the FIRST tail problem alone and return its plan (x*, u*) in x_new / u_new --
     // the stand-alone solve_tvlqr (irs_lqr/tv_lqr.py:30-145); no true-dynamics step is taken
     int single_tail;
+    // ADMM kernel only (may be null): DEV int; the kernel returns at once, touching nothing, when *run_flag == 0 --
+    // the fused iterate (iterate.hip) enqueues the bounded descent behind the test "does any tail's unconstrained plan
+    // leave the box", without a host round trip
+    const int* run_flag;
 };
 
 // position-controlled models expose indices_u_into_x (quasistatic_dynamics.py:57-65)

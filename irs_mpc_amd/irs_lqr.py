@@ -21,6 +21,8 @@ iteration (replaces zmq_parallel_cmp/array_io.py + the worker processes).
 """
 import time
 
+import ctypes
+
 import numpy as np
 import torch
 
@@ -216,10 +218,93 @@ class IrsLqr:
             raise ValueError("TV_LQR failed. Optimization problem is not solved.")
 
     # ---- irs_lqr/irs_lqr.py:188-218 ----------------------------------------
-    def iterate(self, max_iterations):
+    def _fused_spec(self):
+        """(mode, N, sampling) if the whole loop can run inside the library (irs_iterate): the linearisation needs no
+        host closure per time step -- exact, or a GaussianSmoothing drawn on the device -- on one GPU; else None."""
+        return None
+
+    def _iterate_fused(self, max_iterations, spec, timing=None):
+        """IrsLqr.iterate through ONE C-ABI call (include/irs_hip.h, irs_iterate): every descent of the loop is
+        enqueued back to back -- linearise, Riccati + closed-loop rollout + cost, and with finite bounds the plan test
+        and the bounded descent behind its device-side flag; the histories come back in one read at the end.  Same
+        bookkeeping as the loop below: k + 1 descents, the last one logged but not adopted, errors raised where the
+        reference raises them (the lists hold everything up to the failing descent)."""
+        from . import _lib
+        mode, N, smp = spec
+        n_desc = max_iterations - self.iter + 2
+        if n_desc <= 0:
+            return self.x_trj, self.u_trj, self.cost
+        n, m, T, dm = self.dim_x, self.dim_u, self.T, self._dm
+        device = self._Q.device
+        c = _lib.IterateCall()
+        c.model, c.n_params = dm.model_id, dm._np
+        for i, v in enumerate(dm.params):
+            c.params[i] = v
+        c.mode, c.T, c.N, c.n_descents = mode, T, int(N), n_desc
+        if smp is not None:
+            sx = np.stack([smp.stds(self.iter + i)[0] for i in range(n_desc)]).astype(np.float64)
+            su = np.stack([smp.stds(self.iter + i)[1] for i in range(n_desc)]).astype(np.float64)
+            sx, su = np.ascontiguousarray(sx), np.ascontiguousarray(su)
+            c.std_x, c.std_u = sx.ctypes.data, su.ctypes.data
+            c.seed, c.iter0 = int(smp.seed), int(self.iter)
+        c.Q, c.Qd, c.R, c.xd_trj = (t_.data_ptr() for t_ in (self._Q, self._Qd, self._R, self._xd))
+        c.alpha_R = 0.5
+        box = self._box_bounds()
+        if box is not None:
+            c.xlo, c.xhi, c.ulo, c.uhi = (b.data_ptr() for b in box)
+            c.qp_rho = float(getattr(self.params, "qp_rho", 10.0))
+            c.qp_max_iter = int(getattr(self.params, "qp_max_iter", 5000))
+            c.qp_eps = float(getattr(self.params, "qp_eps", 1e-8))
+        x0d, u0d = dev.to_dev(np.asarray(self.x_trj, float)), dev.to_dev(np.asarray(self.u_trj, float))
+        c.x_trj0, c.u_trj0 = x0d.data_ptr(), u0d.data_ptr()
+        xh = torch.empty((n_desc, T + 1, n), dtype=dev.F64, device=device)
+        uh = torch.empty((n_desc, T, m), dtype=dev.F64, device=device)
+        ch = torch.empty((n_desc,), dtype=dev.F64, device=device)
+        ih = torch.zeros((n_desc, 8), dtype=torch.int32, device=device)
+        c.x_hist, c.u_hist, c.cost_hist, c.info_hist = xh.data_ptr(), uh.data_ptr(), ch.data_ptr(), ih.data_ptr()
+        need = self._dm.lib.irs_iterate_scratch_bytes(dm.model_id, mode, T, int(N))
+        scratch = getattr(self, "_fused_scratch", None)
+        if scratch is None or scratch.numel() < need:
+            scratch = self._fused_scratch = torch.empty((need,), dtype=torch.uint8, device=device)
+        c.scratch, c.scratch_bytes = scratch.data_ptr(), scratch.numel()
+        tm = _lib.Timing() if timing is not None else None
+        _lib.check(self._dm.lib.irs_iterate(ctypes.byref(c), ctypes.byref(tm) if tm is not None else None, dev._stream()),
+                   "irs_iterate")
+        if timing is not None:
+            timing.update({k: getattr(tm, k) for k, _ in _lib.Timing._fields_})
+        xs, us, cs, infos = xh.cpu().numpy(), uh.cpu().numpy(), ch.cpu().numpy(), ih.cpu().numpy()     # the ONE read-back
+        self._last = dict(At=None, Bt=None, ct=None, K=None, k=None, info=ih[-1, :1])
+        for i in range(n_desc):
+            row = infos[i]
+            if row[0] != 0:
+                raise ValueError("TV_LQR failed. Optimization problem is not solved.")
+            if row[1] != 0:
+                raise ValueError("randomized-smoothing least squares is rank deficient (Gram matrix not positive "
+                                 "definite; need more samples or a non-zero std)")
+            if row[6] != 0:
+                raise NotImplementedError(
+                    "a box bound is active and horizon T=%d does not fit the LDS-resident factorisation of the "
+                    "bounded TV-LQR kernel (tv_lqr.py:112-123)" % self.T)
+            if row[2] != 0 and row[5] != 0:
+                raise ValueError("TV_LQR failed. Optimization problem is not solved.")
+            self.x_trj_lst.append(xs[i])
+            self.u_trj_lst.append(us[i])
+            self.cost_lst.append(float(cs[i]))
+            if self.iter > max_iterations:
+                break
+            self.cost, self.x_trj, self.u_trj = float(cs[i]), xs[i], us[i]
+            self.iter += 1
+        return self.x_trj, self.u_trj, self.cost
+
+    def iterate(self, max_iterations, timing=None):
         """irs_lqr/irs_lqr.py:188-218: max_iterations+1 descents, the last one logged but
-        not adopted.  Per iteration: 2 kernel launches (3 with host-drawn samples' upload)
-        and one read-back of (x_new, u_new, cost) for the history lists."""
+        not adopted.  Quiet runs whose linearisation needs no host closure go through ONE library call
+        (`_iterate_fused`); otherwise, per iteration: 2 kernel launches (3 with host-drawn samples' upload)
+        and one read-back of (x_new, u_new, cost) for the history lists.  `timing` (a dict, fused path only):
+        filled with the library's per-phase device times (irs_timing)."""
+        spec = self._fused_spec()
+        if spec is not None and not self.verbose:
+            return self._iterate_fused(max_iterations, spec, timing)
         x_dev = dev.to_dev(np.asarray(self.x_trj, float))
         u_dev = dev.to_dev(np.asarray(self.u_trj, float))
         while True:
@@ -271,6 +356,12 @@ class _IrsLqrSampled(IrsLqr):
             dxs.append(np.asarray(dx, np.float32))
             dus.append(np.asarray(du, np.float32))
         return np.stack(dxs), np.stack(dus)
+
+    def _fused_spec(self):
+        on_device = isinstance(self.sampling, GaussianSmoothing) and getattr(self.sampling, "on_device", True)
+        if not on_device or dist_util.rank_world()[1] != 1:
+            return None
+        return self.MODE, self.sampling.num_samples, self.sampling
 
     def _get_TV_matrices_dev(self, x_trj, u_trj):
         rank, world = dist_util.rank_world()
@@ -335,6 +426,10 @@ class IrsLqrFirstOrder(_IrsLqrSampled):
 
 class IrsLqrExact(IrsLqr):
     """irs_lqr/irs_lqr_exact.py:6-31."""
+
+    def _fused_spec(self):
+        from ._lib import ITERATE_EXACT
+        return ITERATE_EXACT, 0, None
 
     def _get_TV_matrices_dev(self, x_trj, u_trj):
         return self._dm.exact_linearize(x_trj, u_trj)

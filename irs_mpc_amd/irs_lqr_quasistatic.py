@@ -270,7 +270,41 @@ class IrsLqrQuasistatic(QuasistaticOptimizerBase):
             # like solve_tvlqr's `raise ValueError` when the solver fails (tv_lqr.py:139-140)
             raise ValueError("TV_LQR failed. Optimization problem is not solved.")
 
-    # ---- outer loop (QuasistaticOptimizerBase.iterate): the trajectory stays on the device -------
+    # ---- outer loop: the trajectory stays on the device ------------------------------------------------
+    def iterate(self, max_iterations):
+        """irs_lqr_quasistatic.py:347-390.  A quiet run (verbose = False, no trajectory publishing) enqueues ALL its
+        descents -- sample pass, bound rows, the T re-solved tail QPs with the contact dynamics in the loop -- without
+        ever waiting for the device: every descent linearises around the device-resident result of the previous one,
+        and trajectories, costs and solver flags are read back ONCE at the end, where the reference's bookkeeping
+        (history lists, five cost terms, best-so-far, the ValueError of a failed solve) is replayed in order.  A
+        verbose run prints a cost per iteration and therefore synchronises per iteration (the base-class loop)."""
+        if self.verbose or self.publish_every_iteration:
+            return super().iterate(max_iterations)
+        state, it0, recs = self._start(), self.current_iter, []
+        while True:
+            x_new_d, u_new_d, _ = self._local_descent_dev(*state)
+            recs.append((x_new_d, u_new_d, self._last["info"], self._smooth_info))
+            if self.current_iter > max_iterations:
+                break
+            state = (x_new_d, u_new_d)
+            self.current_iter += 1
+        xs = torch.stack([r[0] for r in recs]).cpu().numpy()            # the one read-back
+        us = torch.stack([r[1] for r in recs]).cpu().numpy()
+        infos = torch.stack([r[2] for r in recs]).cpu().numpy()
+        sbad = torch.stack([(r[3] != 0).any() for r in recs]).cpu().numpy()
+        self.current_iter = it0
+        for i in range(len(recs)):
+            if sbad[i]:
+                raise ValueError("randomized-smoothing least squares is rank deficient")
+            if infos[i][0] != 0 or infos[i][2] != 0:
+                raise ValueError("TV_LQR failed. Optimization problem is not solved.")    # tv_lqr.py:139-140
+            cost_new = self._log(xs[i], us[i])
+            if self.current_iter > max_iterations:
+                break
+            self.cost, self.x_trj, self.u_trj = cost_new, xs[i], us[i]
+            self.current_iter += 1
+        return self.x_trj, self.u_trj, self.cost
+
     def _start(self):
         return dev.to_dev(np.asarray(self.x_trj, float)), dev.to_dev(np.asarray(self.u_trj, float))
 

@@ -2360,3 +2360,114 @@ def test_reference_script_text_runs_through_the_import_shim(amd, golden_dir, tmp
         # bicycle: the steer bound is active; the reference's curve carries OSQP's 1e-3 accuracy per tail QP
         np.testing.assert_allclose(costs[0], gold[0], rtol=1e-9)
         np.testing.assert_allclose(costs[1], gold[1], rtol=2e-2)
+
+
+# ---------------------------------------------------------------- the fused iterate at the boundary (round 3)
+@pytest.mark.parametrize("name,cls,N,iters", [("pendulum", "IrsLqrZeroOrder", 2000, 5), ("quadrotor", "IrsLqrFirstOrder", 400, 3),
+                                              ("pendulum", "IrsLqrExact", 0, 6), ("bicycle", "IrsLqrExact", 0, 3),
+                                              ("bicycle", "IrsLqrZeroOrder", 3000, 2)])
+def test_fused_iterate_equals_the_host_loop(amd, name, cls, N, iters, capsys):
+    """IrsLqr.iterate through ONE library call (irs_iterate, csrc/iterate.hip: every descent enqueued back to back, the
+    histories read back once) == the host loop (a verbose run: one read-back per iteration) -- same kernels, same
+    Philox counters: bit for bit, for the sampled estimators, the exact one, and with an ACTIVE box bound (bicycle:
+    the steer limit binds, the plan test raises its flag on the device and the bounded descent runs behind it)."""
+    from examples.problems import PROBLEMS
+    T = {"pendulum": 40, "quadrotor": 30, "bicycle": 40}[name]
+
+    def make(verbose):
+        sysd, params, sm, _, _ = PROBLEMS[name](T)
+        if cls == "IrsLqrExact":
+            sol = amd.IrsLqrExact(sysd, params)
+        else:
+            smp = amd.GaussianSmoothing(sm["std_x"], sm["std_u"], N, power=sm["power"], seed=5)
+            sol = getattr(amd, cls)(sysd, params, smp)
+        sol.verbose = verbose
+        return sol
+
+    a, b = make(False), make(True)
+    timing = {}
+    ra = a.iterate(iters, timing=timing)
+    rb = b.iterate(iters)
+    capsys.readouterr()
+    assert len(a.cost_lst) == len(b.cost_lst) == iters + 2 and a.iter == b.iter
+    # (with an active bound the fused path takes the cost the bounded-descent kernel accumulates, the host loop a
+    # separate irs_evaluate_cost launch: the same sum in another order)
+    np.testing.assert_allclose(np.array(a.cost_lst), np.array(b.cost_lst), rtol=1e-13 if name == "bicycle" else 0, atol=0)
+    for xa, xb in zip(a.x_trj_lst, b.x_trj_lst):
+        np.testing.assert_array_equal(xa, xb)
+    for ua, ub in zip(a.u_trj_lst, b.u_trj_lst):
+        np.testing.assert_array_equal(ua, ub)
+    np.testing.assert_array_equal(ra[0], rb[0])
+    assert abs(ra[2] - rb[2]) <= 1e-13 * abs(rb[2]) and a.cost_lst[-1] < a.cost_lst[0]
+    # irs_timing (SURVEY 8(b) irs_get_timing): per-phase device time of the loop
+    assert timing["descents"] == iters + 1 and timing["descent_ms"] > 0 and timing["linearise_ms"] > 0
+    assert timing["sample_steps"] == (iters + 1) * T * N
+    if name == "bicycle":
+        assert getattr(b, "_box_used", False)              # the bound was active in the host loop's last descent
+    # a second call continues where the first stopped, like the reference's loop
+    a.iterate(iters + 1)
+    b.iterate(iters + 1)
+    capsys.readouterr()
+    np.testing.assert_allclose(np.array(a.cost_lst), np.array(b.cost_lst), rtol=1e-13 if name == "bicycle" else 0, atol=0)
+
+
+def test_plan_within_bounds_kernel_vs_host_statement(amd):
+    """irs_tvlqr_plan_within_bounds (one thread per tail, all tails advancing together) against the host's
+    `_tail_plans_within_bounds` on the bicycle problem, with the steer limit loosened step by step until no plan
+    touches it."""
+    from irs_mpc_amd import _lib, device as dev
+    from examples.problems import bicycle
+    T = 60
+    sysd, params, _, _, _ = bicycle(T)
+    seen = set()
+    for steer in (0.1, np.pi / 4, 1.5, 1e4):
+        params.xbound = [-np.array([1e4, 1e4, 1e4, 1e4, steer]), np.array([1e4, 1e4, 1e4, 1e4, steer])]
+        sol = amd.IrsLqrExact(sysd, params)
+        sol.verbose = False
+        x, u = dev.to_dev(sol.x_trj), dev.to_dev(sol.u_trj)
+        At, Bt, ct = sol._get_TV_matrices_dev(x, u)
+        o = sol._dm.tvlqr_descent(At, Bt, ct, sol._Q, sol._Qd, sol._R, sol._xd, x[0].contiguous(), alpha_R=0.5)
+        box = sol._box_bounds()
+        want = sol._tail_plans_within_bounds(At, Bt, ct, o["K"], o["k"], o["x_new"])
+        flag = torch.full((1,), -7, dtype=torch.int32, device=x.device)
+        _lib.check(_lib.load().irs_tvlqr_plan_within_bounds(5, 2, T, At.data_ptr(), Bt.data_ptr(), ct.data_ptr(),
+                                                           o["K"].data_ptr(), o["k"].data_ptr(), o["x_new"].data_ptr(),
+                                                           *(b.data_ptr() for b in box), flag.data_ptr(), dev._stream()),
+                   "irs_tvlqr_plan_within_bounds")
+        assert int(flag.item()) == (0 if want else 1), steer
+        seen.add(bool(want))
+    assert seen == {True, False}
+
+
+def test_quasistatic_iterate_without_host_synchronisation(amd, capsys):
+    """IrsLqrQuasistatic.iterate, quiet: all descents enqueued, one read-back, the reference's bookkeeping replayed
+    afterwards == the verbose run (one read-back per iteration), bit for bit, on device-drawn samples."""
+    from examples.run_quasistatic import problem
+    T, N = 12, 1500
+
+    def make(verbose):
+        q_dynamics, x0, u_traj_0, Q_dict, Qd_dict, R_dict, x_trj_d = problem(T, 0.1)
+        p = amd.IrsLqrQuasistaticParameters()
+        p.Q_dict, p.Qd_dict, p.R_dict = Q_dict, Qd_dict, R_dict
+        p.x0, p.x_trj_d, p.u_trj_0, p.T = x0, x_trj_d, u_traj_0, T
+        p.u_bounds_abs = np.array([-np.ones(4) * 0.05, np.ones(4) * 0.05])
+        p.sampling = lambda u_initial, it: u_initial / (it ** 0.8)
+        p.std_u_initial, p.num_samples = np.ones(4) * 0.3, N
+        p.publish_every_iteration = False
+        p.device_rng_seed = 3
+        sol = amd.IrsLqrQuasistatic(q_dynamics, p)
+        sol.verbose = verbose
+        return sol
+
+    a, b = make(False), make(True)
+    ra, rb = a.iterate(4), b.iterate(4)
+    capsys.readouterr()
+    assert len(a.cost_all_list) == len(b.cost_all_list) == 6 and a.current_iter == b.current_iter == 5
+    np.testing.assert_array_equal(np.array(a.cost_all_list), np.array(b.cost_all_list))
+    for k in ("Qu", "Qu_final", "Qa", "Qa_final", "R"):
+        np.testing.assert_array_equal(getattr(a, "cost_%s_list" % k), getattr(b, "cost_%s_list" % k))
+    for xa, xb in zip(a.x_trj_list, b.x_trj_list):
+        np.testing.assert_array_equal(xa, xb)
+    np.testing.assert_array_equal(ra[0], rb[0])
+    np.testing.assert_array_equal(a.x_trj_best, b.x_trj_best)
+    assert a.cost_best == b.cost_best < a.cost_all_list[0]
