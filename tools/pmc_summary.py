@@ -29,7 +29,7 @@ def short(name):
                 w, T, N = SIZES[k]
                 return "%s_%s_T%d_N%d" % (w, tag, T, N)
         return None
-    if "ctrlbox" in name and "descent" in name:
+    if "ctrlbox" in name and ("descent" in name or "mfma_kernel" in name):
         for k in ("PlanarHandExact", "PlanarHand", "BoxPivotExact", "BoxPivot"):
             if k in name:
                 return "%s_ctrlbox_descent_T%d" % (SIZES[k][0], SIZES[k][1])

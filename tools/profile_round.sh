@@ -20,6 +20,16 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_pendulum -- python3 $R/bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-secondary --workload pendulum > $OUT/stats_pendulum.log 2>&1
 echo "per-workload stats rc=$?"
 if [ "$2" = "stats-only" ]; then cd $R; python tools/pmc_summary.py $OUT $TAG > /dev/null; rm -rf $OUT/stats $OUT/stats_*/ ; exit 0; fi
+# matrix-core evidence for the bounded descent (ctrlbox_mfma_kernel: 2 waves, f64 MFMA) -- the loop of the main workload runs it
+for C in SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py $ARGS --no-secondary > $OUT/pmc_$C.log 2>&1
+  echo "pass $C (planar_hand loop: descent kernel) rc=$?"
+done
+# LDS side of the uniform-geometry kernel (table lookups)
+for C in SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_VALU; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py $ARGS --no-secondary > $OUT/pmc_$C.log 2>&1
+  echo "pass $C (planar_hand zero-order-B) rc=$?"
+done
 for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py $ARGS --no-secondary > $OUT/pmc_$C.log 2>&1
   echo "pass $C (planar_hand zero-order-B, exact step QP) rc=$?"

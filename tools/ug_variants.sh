@@ -9,7 +9,7 @@ FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -Wall -Wno-
 while [ $# -ge 2 ]; do
   TAG=$1; EXTRA=$2; shift 2
   /opt/rocm/bin/hipcc $FLAGS $EXTRA -c smooth_ug.hip -o variants/smooth_ug_$TAG.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libirs_hip_$TAG.so plugin.o smooth.o variants/smooth_ug_$TAG.o tvlqr.o cem.o boxqp.o ctrlbox.o ctrlbox_mfma.o collective.o -ldl
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libirs_hip_$TAG.so plugin.o smooth.o variants/smooth_ug_$TAG.o tvlqr.o cem.o boxqp.o ctrlbox.o ctrlbox_mfma.o collective.o iterate.o -ldl
   rm variants/smooth_ug_$TAG.o
   echo built $TAG
 done
