@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kSelBlock) void cem_select_kernel(const double* __r
                                                                int n_elite, int* __restrict__ elite_idx) {
     __shared__ unsigned int hist[256];
     __shared__ unsigned long long s_prefix;
-    __shared__ int s_k;
+    __shared__ int s_k, s_binc;
     __shared__ int scan[kSelBlock];
     __shared__ int s_less_total;
     const int tid = threadIdx.x;
@@ -157,19 +157,47 @@ __global__ __launch_bounds__(kSelBlock) void cem_select_kernel(const double* __r
             if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 0xFF], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            int k = s_k, bin = 0;
-            for (; bin < 256; ++bin) {
-                int c = (int)hist[bin];
-                if (k <= c) break;
-                k -= c;
+        if (tid < 64) {
+            // the bin holding the k-th smallest candidate: inclusive prefix sums of the 256 counts, four per lane
+            // (one wave; the serial scan by one lane was 8 x 256 dependent LDS reads of the kernel's 74 us)
+            const int k = s_k;
+            int c[4], run = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { c[j] = (int)hist[4 * tid + j]; run += c[j]; }
+            int incl = run;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(incl, off, 64);
+                if (tid >= off) incl += v;
             }
-            s_k = k;                                   // rank inside the chosen bin
-            s_prefix = prefix | ((unsigned long long)bin << shift);
+            int before = incl - run;                   // candidates in the bins of lower lanes
+            const bool mine = before < k && k <= incl; // exactly one lane
+            if (mine) {
+                int bin = 4 * tid, kk = k - before;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (kk > c[j] && j < 3) { kk -= c[j]; ++bin; } else break;
+                }
+                s_k = kk;                              // rank inside the chosen bin
+                s_prefix = prefix | ((unsigned long long)bin << shift);
+                s_binc = (int)hist[bin];
+            }
         }
         __syncthreads();
+        // every key of the chosen bin is elite: no need to refine further -- the largest key of the bin is a valid
+        // threshold (keys equal to it, if any, all belong)
+        const bool whole_bin = s_k == s_binc && pass < 7;
+        __syncthreads();                               // everyone has read the pair before lane 0 rewrites it
+        if (whole_bin) {
+            if (tid == 0) {
+                s_prefix |= (1ull << shift) - 1ull;
+                s_k = 0x7fffffff;
+            }
+            __syncthreads();
+            break;
+        }
     }
-    const unsigned long long thr = s_prefix;           // key of the n_elite-th smallest cost
+    const unsigned long long thr = s_prefix;           // key of the n_elite-th smallest cost (or the top of its bin)
     const int need_equal = s_k;                        // how many keys == thr belong to the elite
     // ordered compaction: thread owns a contiguous chunk of indices
     const int chunk = (B + kSelBlock - 1) / kSelBlock;
@@ -210,22 +238,48 @@ __global__ __launch_bounds__(kSelBlock) void cem_select_kernel(const double* __r
     }
 }
 
-// u_new = mean over elites, std_new = population std over elites (np.mean / np.std, axis 0).
-__global__ void cem_refit_kernel(const double* __restrict__ u_cand, const int* __restrict__ elite_idx,
-                                 int n_elite, int Tm, double* __restrict__ u_new,
-                                 double* __restrict__ std_new) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= Tm) return;
+// u_new = mean over elites, std_new = population std over elites (np.mean / np.std, axis 0: two passes).
+// One workgroup per 64 consecutive outputs q: lane = q (an elite's row is contiguous in q: coalesced), the 16 waves
+// split the elites and meet in LDS, partial sums added in wave order (deterministic).  (One lane per q looping over
+// all elites alone -- 2 x n_elite dependent loads -- took 118 us for 312 elites.)
+constexpr int kRefitWaves = 16;
+__global__ __launch_bounds__(64 * kRefitWaves) void cem_refit_kernel(const double* __restrict__ u_cand,
+                                                                     const int* __restrict__ elite_idx, int n_elite,
+                                                                     int Tm, double* __restrict__ u_new,
+                                                                     double* __restrict__ std_new) {
+    __shared__ double part[kRefitWaves][64];
+    __shared__ double mean_s[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + lane;
+    const bool on = q < Tm;
     double s = 0.0;
-    for (int e = 0; e < n_elite; ++e) s += u_cand[(size_t)elite_idx[e] * Tm + q];
-    const double mean = s / n_elite;
+    for (int e = wave; e < n_elite; e += kRefitWaves)
+        s += on ? u_cand[(size_t)elite_idx[e] * Tm + q] : 0.0;
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kRefitWaves; ++w) t += part[w][lane];
+        mean_s[lane] = t / n_elite;
+    }
+    __syncthreads();
+    const double mean = mean_s[lane];
     double v = 0.0;
-    for (int e = 0; e < n_elite; ++e) {
-        double d = u_cand[(size_t)elite_idx[e] * Tm + q] - mean;
+    for (int e = wave; e < n_elite; e += kRefitWaves) {
+        const double d = on ? u_cand[(size_t)elite_idx[e] * Tm + q] - mean : 0.0;
         v += d * d;
     }
-    u_new[q] = mean;
-    std_new[q] = sqrt(v / n_elite);
+    __syncthreads();
+    part[wave][lane] = v;
+    __syncthreads();
+    if (wave == 0 && on) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kRefitWaves; ++w) t += part[w][lane];
+        u_new[q] = mean;
+        std_new[q] = sqrt(t / n_elite);
+    }
 }
 
 }  // namespace
@@ -281,8 +335,8 @@ int irs_cem_refit(int T, int m, int B, int n_elite, const double* u_cand, const 
     hipLaunchKernelGGL(cem_select_kernel, dim3(1), dim3(kSelBlock), 0, st, costs, B, n_elite, elite_idx);
     IRS_CHECK_LAUNCH();
     const int Tm = T * m;
-    hipLaunchKernelGGL(cem_refit_kernel, dim3((Tm + 63) / 64), dim3(64), 0, st, u_cand, elite_idx, n_elite, Tm,
-                       u_new, std_new);
+    hipLaunchKernelGGL(cem_refit_kernel, dim3((Tm + 63) / 64), dim3(64 * kRefitWaves), 0, st, u_cand, elite_idx, n_elite,
+                       Tm, u_new, std_new);
     IRS_CHECK_LAUNCH();
     return IRS_OK;
 }

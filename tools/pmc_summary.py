@@ -27,6 +27,8 @@ def short(name):
         for k in ("PlanarHandExact", "PlanarHand", "BoxPivotExact", "BoxPivot", "Quadrotor", "Pendulum"):
             if k in model:
                 w, T, N = SIZES[k]
+                if k == "PlanarHandExact" and mode in (1, 2) and "smooth_ug_kernel" not in name:
+                    w += "_general"         # the general contact kernel (IRS_UG=0 sub-report); the default is smooth_ug_kernel
                 return "%s_%s_T%d_N%d" % (w, tag, T, N)
         return None
     if "ctrlbox" in name and ("descent" in name or "mfma_kernel" in name):
