@@ -43,7 +43,6 @@ __global__ __launch_bounds__(BLOCK) void smooth_kernel(SmoothArgs a) {
     using TR = SmoothTraits<Model, MODE>;
     constexpr int n = TR::n, m = TR::m, d = TR::d, NZ = TR::NZ, Z0 = TR::Z0, P = TR::P;
     constexpr int NW = BLOCK / 64;
-    constexpr int P4 = (P + 3) / 4 * 4;     // row stride of the partial buffer (16-byte rows)
     // matrix-core Gram path: zero-order, one 16-wide tile, too many statistics for registers
     constexpr bool USE_MFMA = MODE == IRS_SMOOTH_ZERO_ORDER_AB && d <= 16 && n <= 16 && TR::PP > 64 &&
                               BLOCK == kBlock;
