@@ -47,7 +47,7 @@ constexpr int kUgPdas = IRS_UG_PDAS;          // primal-dual active-set iteratio
 constexpr int kUgTabStride = 76;              // floats per table entry: 64 (G', column-major) + 8 (tau: 1 off the reduced
                                               // set, 0 on it) + the reduced set + pad; 304 B: 16-byte aligned rows
 #ifndef IRS_UG_NOM_ROUNDS
-#define IRS_UG_NOM_ROUNDS 3
+#define IRS_UG_NOM_ROUNDS 2
 #endif
 constexpr int kUgNomRounds = IRS_UG_NOM_ROUNDS;   // sample rounds the nominal wave sits out (its f64 step takes about that long)
 constexpr int kUgRing = 128;                  // parked samples per wave: < 64 waiting + <= 64 new ones
@@ -240,36 +240,36 @@ __device__ __forceinline__ void ug_full(const UgLds<Model>& S, const float* r, f
             wp[4] = hi.x; wp[5] = hi.y; wp[6] = hi.z; wp[7] = hi.w;
         }
         ug_lookup<Model>(S, a, wp, 0.f, u, tau);
-        float wpp = 0.f, gp = 0.f, zp = 0.f;
+        // in arithmetic rather than selects (tau_i = 1 off the reduced set, 0 on it): rho = -(1 - tau) u on the set,
+        // the slack rates s = tau u off it -- a third of the instructions of the select form (400 -> ~270 per step)
+        const float wpp = S.Wd[pp];
+        float gp = 0.f, zp = 0.f;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const bool isp = i == pp;
-            wpp = isp ? wp[i] : wpp;
             gp = isp ? g[i] : gp;
             zp = isp ? u[i] : zp;
         }
         const bool full_ok = zp > piv_rel * wpp;
         const float t2 = full_ok ? -gp * irs_rcp_fast(zp) : kBig;
+        float rho[NC], qv[NC];
         float t1 = kBig;
-        int kb = 0;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
-            const bool in = tau[i] == 0.f;
-            const float rho = -u[i];
-            const bool cand = in && rho > 0.f;
-            const float qv = cand ? lam[i] * irs_rcp_fast(rho) : kBig;
-            if (qv < t1) { t1 = qv; kb = i; }
+            rho[i] = fmaf(tau[i], u[i], -u[i]);
+            qv[i] = rho[i] > 0.f ? lam[i] * irs_rcp_fast(rho[i]) : kBig;
+            t1 = fminf(t1, qv[i]);
         }
+        int kb = 0;                                        // the FIRST row that attains the minimum
+#pragma unroll
+        for (int i = NC - 1; i >= 0; --i) kb = (qv[i] == t1) ? i : kb;
         const float tmin = fminf(t1, t2);
         if (!done && !(tmin < kBig)) done = true;          // no step possible: infeasible primal, keep lam
         const float tt = done ? 0.f : tmin;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
-            const bool in = tau[i] == 0.f;
-            const float rho = in ? -u[i] : 0.f;
-            const float s = in ? 0.f : u[i];
-            g[i] = fmaf(tt, s, g[i]);
-            lam[i] = fmaxf(lam[i] - tt * rho + ((i == pp) ? tt : 0.f), 0.f);
+            g[i] = fmaf(tt * tau[i], u[i], g[i]);
+            lam[i] = fmaxf(fmaf(-tt, rho[i], lam[i]) + ((i == pp) ? tt : 0.f), 0.f);
         }
         if (!done) {
             const bool full = t2 <= t1;
@@ -365,9 +365,42 @@ struct UgNomLds {
     double q[7], Dinv[7], b[7];
 };
 
+// (a) the f64 geometry: independent of the f32 prologue and of the table, so the nominal wave runs it BEFORE the
+// workgroup's first barrier, beside wave 0's f32 assembly.  Leaves J, q, D^-1, b in LDS and returns r_c on lane c.
+template <class Model>
+__device__ __forceinline__ double ug_nominal_geometry(const SmoothArgs& a, UgNomLds& L, int t, int lane) {
+    constexpr int NC = Model::NC, n = Model::NX, m = Model::NU;
+    double x64[n], u64[m], q[n], Dinv[n], b[n], J[NC][n], phi[NC];
+#pragma unroll
+    for (int i = 0; i < n; ++i) x64[i] = a.x_trj[(size_t)t * n + i];
+#pragma unroll
+    for (int j = 0; j < m; ++j) u64[j] = a.u_trj[(size_t)t * m + j];
+    Model::template assemble<double>(a.p, x64, u64, q, Dinv, b, J, phi);
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int k = 0; k < n; ++k) L.J[c][k] = J[c][k];
+#pragma unroll
+        for (int k = 0; k < n; ++k) { L.q[k] = q[k]; L.Dinv[k] = Dinv[k]; L.b[k] = b[k]; }
+    }
+    // r_c on lane c (phi is the only per-row quantity not in LDS)
+    double rr = 0.0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        double s = phi[c];
+#pragma unroll
+        for (int k = 0; k < n; ++k) s -= J[c][k] * (b[k] * Dinv[k]);
+        rr = (lane == c) ? s : rr;
+    }
+    wave_sync();
+    return rr;
+}
+
+// (b) after the table exists: the f32 pipeline's active set at du = 0, then the cooperative f64 solve and its check
 template <class Model>
 __device__ __forceinline__ void ug_nominal(const SmoothArgs& a, const UgUni<Model::NC>& U, const UgLds<Model>& S,
-                                           UgNomLds& L, int t, int lane) {
+                                           UgNomLds& L, double rr, int t, int lane) {
     constexpr int NC = Model::NC, n = Model::NX, m = Model::NU;
     static_assert(NC == 8 && n <= 8, "lane (i,k) = 8 i + k owns entry (i,k) of the 8 x 8 dual Hessian");
     // (1) the f32 pipeline at du = 0: the active set (every lane computes the same)
@@ -381,32 +414,7 @@ __device__ __forceinline__ void ug_nominal(const SmoothArgs& a, const UgUni<Mode
 #pragma unroll
     for (int i = 0; i < NC; ++i) set |= (lam32[i] > 0.f) ? (1u << i) : 0u;
     set = (unsigned)__builtin_amdgcn_readfirstlane((int)set);
-    // (2) geometry in f64; the rows go to LDS as they are produced
     {
-        double x64[n], u64[m], q[n], Dinv[n], b[n], J[NC][n], phi[NC];
-#pragma unroll
-        for (int i = 0; i < n; ++i) x64[i] = a.x_trj[(size_t)t * n + i];
-#pragma unroll
-        for (int j = 0; j < m; ++j) u64[j] = a.u_trj[(size_t)t * m + j];
-        Model::template assemble<double>(a.p, x64, u64, q, Dinv, b, J, phi);
-        if (lane == 0) {
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
-#pragma unroll
-                for (int k = 0; k < n; ++k) L.J[c][k] = J[c][k];
-#pragma unroll
-            for (int k = 0; k < n; ++k) { L.q[k] = q[k]; L.Dinv[k] = Dinv[k]; L.b[k] = b[k]; }
-        }
-        // r_c on lane c (phi is the only per-row quantity not in LDS)
-        double rr = 0.0;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            double s = phi[c];
-#pragma unroll
-            for (int k = 0; k < n; ++k) s -= J[c][k] * (b[k] * Dinv[k]);
-            rr = (lane == c) ? s : rr;
-        }
-        wave_sync();
         // entry (i,k) of W on lane 8 i + k
         const int li = lane >> 3, lk = lane & 7;
         double w = 0.0;
@@ -527,7 +535,10 @@ __global__ __launch_bounds__(kUgBlock) void smooth_ug_kernel(SmoothArgs a) {
     const int lane = tid & 63, wave = tid >> 6;
 
     UG_STAMP(0);
-    // ---- prologue: the timestep's geometry (wave 0), then the table (everyone) ------------------------------
+    // ---- prologue: the timestep's geometry (wave 0; the nominal wave its f64 twin), then the table (everyone) ------
+    const bool nominal_wave = blk == 0 && wave == NW - 1;
+    double nom_r = 0.0;
+    if (nominal_wave && !(a.diag & 2)) nom_r = ug_nominal_geometry<Model>(a, nomL, t, lane);
     if (wave == 0) {
         // the model's QP assembly (trigonometry, closest points): one wave, every lane the same; lane 0 stores
         float xb[n], ub[m], q[n], Dinv[n], b0[n], J[NC][n], phi[NC];
@@ -605,8 +616,7 @@ __global__ __launch_bounds__(kUgBlock) void smooth_ug_kernel(SmoothArgs a) {
 #pragma unroll
     for (int i = 0; i < PPI; ++i) acc[i] = 0.f;
 
-    const bool nominal_wave = blk == 0 && wave == NW - 1;
-    if (nominal_wave && !(a.diag & 2)) ug_nominal<Model>(a, U, S, nomL, t, lane);
+    if (nominal_wave && !(a.diag & 2)) ug_nominal<Model>(a, U, S, nomL, nom_r, t, lane);
     if (nominal_wave) UG_STAMP(8);
     if (!(a.diag & 8)) {
         // 64-sample blocks are dealt round robin to the waves of the timestep: rounds 0 .. kUgNomRounds - 1 to all but
