@@ -157,7 +157,12 @@ int irs_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
  * least-squares solve.  Samples SUPPLIED: dx (T,N,n), du (T,N,m) DEV f32 -- what the
  * reference's `sampling(x_t,u_t,iter)` closure returned at each t, e.g.
  * examples/pendulum/pendulum_zero_order.py:38-43 ("identical seeds").
- * Outputs as irs_smooth_accumulate (sums) + irs_smooth_finalize (At,Bt,ct,info).   */
+ * Outputs as irs_smooth_accumulate (sums) + irs_smooth_finalize (At,Bt,ct,info).
+ * Kernels: csrc/smooth.hip (general sample pass), except IRS_MODEL_PLANAR_HAND_EXACT in the u-only modes
+ * (IRS_SMOOTH_ZERO_ORDER_B, IRS_SMOOTH_FIRST_ORDER) -- quasistatic_dynamics.py:193-266, the state is not perturbed --
+ * which run csrc/smooth_ug.hip: one dual Hessian per timestep, all 2^8 active-set maps tabulated in LDS, every
+ * sample's step QP solved exactly by table rows.  Same arguments, statistics layout and results (to f32 rounding);
+ * the environment variable IRS_UG=0 (read per call) selects the general kernel for comparison runs.             */
 int irs_smooth(int model, const double *params, int n_params, int mode, int T, int N,
                const double *x_trj, const double *u_trj, const float *dx, const float *du,
                double *sums, double *At, double *Bt, double *ct, int *info,
