@@ -2516,3 +2516,61 @@ def test_cem_quasistatic_box_pivoting_full_size(amd):
     # (no descent asserted: on this problem CEM at this budget hovers around its initial cost -- 10 203 -> ~10 230 --
     # which is what the comparison of bench.py / the paper shows; iRS-LQR reaches ~6 000 at the same budget)
     assert len(sol.cost_all_list) == 4 and np.isfinite(sol.cost_all_list).all() and sol.current_iter == 3
+
+
+# ---------------------------------------------------------------- uniform-geometry kernel on unusual geometry (round 3)
+def test_uniform_geometry_kernel_on_random_states(amd):
+    """csrc/smooth_ug.hip (the table-driven pass of the exact 8-row model) against the general kernel (IRS_UG=0) and the
+    oracle on nominal points that are NOT a settled grasp: separated (no row active for any sample), touching, deeply
+    penetrating (up to 7 rows active), with small and large command noise, one time step per point; plus the degenerate
+    sizes N = 1 and T = 1.  Same statistics layout, same (A, B, c) to the f32 tolerance; bit-reproducible."""
+    from irs_mpc_amd import device as dev
+    from irs_mpc_amd._lib import SMOOTH_FIRST_ORDER, SMOOTH_ZERO_ORDER_B
+    rng = np.random.default_rng(99)
+    k, N = 24, 1200
+    obj = np.stack([rng.uniform(-0.3, 0.3, k), rng.uniform(0.1, 0.7, k), rng.uniform(-1, 1, k)], 1)
+    left = np.stack([rng.uniform(-2.2, -0.2, k), rng.uniform(-1.5, 0.5, k)], 1)
+    right = np.stack([rng.uniform(0.2, 2.2, k), rng.uniform(-0.5, 1.5, k)], 1)
+    X = np.zeros((k, 7))
+    X[:, HAND.PERM] = np.hstack([obj, left, right])
+    X[0, HAND.PERM] = [0.0, 2.0, 0.0, -2.5, 0.0, 2.5, 0.0]            # far away: no contact whatever the command
+    U = X[:, HAND_IDX] + rng.normal(0, 0.1, (k, 4))
+    sys_o = orc.PlanarHandOracle(0.1)
+    dm = amd.PlanarHandDynamics(0.1).dm()
+    xd, ud = dev.to_dev(X), dev.to_dev(U)
+    for std in (0.02, 0.5):
+        du = (std * rng.normal(size=(k, N, 4))).astype(np.float32)
+        dud = dev.to_dev(du, dev.F32)
+        for mode in (SMOOTH_ZERO_ORDER_B, SMOOTH_FIRST_ORDER):
+            outs = {}
+            for ug in ("1", "0"):
+                os.environ["IRS_UG"] = ug
+                try:
+                    o = dm.smooth(mode, xd, ud, None, dud)
+                    outs[ug] = {kk: o[kk].cpu().numpy() for kk in ("At", "Bt", "ct", "info", "sums")}
+                finally:
+                    os.environ.pop("IRS_UG", None)
+            assert int(np.abs(outs["1"]["info"]).sum()) == 0
+            np.testing.assert_array_equal(outs["1"]["At"], outs["0"]["At"])
+            if mode == SMOOTH_ZERO_ORDER_B:
+                np.testing.assert_allclose(outs["1"]["Bt"], outs["0"]["Bt"], **FP32_TOL)
+                np.testing.assert_allclose(outs["1"]["ct"], outs["0"]["ct"], **FP32_TOL)
+                xp = np.vstack([X, X[-1:]])
+                _, Bo, co = orc.zero_order_B_decoupled(sys_o, xp, U, du.astype(np.float64))
+                np.testing.assert_allclose(outs["1"]["Bt"], Bo, **FP32_TOL)
+                np.testing.assert_allclose(outs["1"]["ct"], co, **FP32_TOL)
+            else:
+                # piecewise constant in the sample: the two f32 routes may put a borderline sample on different faces
+                assert np.abs(outs["1"]["Bt"] - outs["0"]["Bt"]).max() < 20.0 / N
+            o2 = dm.smooth(mode, xd, ud, None, dud)
+            assert np.array_equal(o2["Bt"].cpu().numpy(), outs["1"]["Bt"]) and np.array_equal(o2["ct"].cpu().numpy(), outs["1"]["ct"])
+    assert np.abs(outs["1"]["Bt"][0][HAND.PERM[:3]]).max() == 0.0       # the far-away point: the disc does not see the command
+    # degenerate sizes
+    for T1, N1 in ((1, 1), (1, 70), (3, 1)):
+        du1 = (0.1 * rng.normal(size=(T1, N1, 4))).astype(np.float32)
+        o = dm.smooth(SMOOTH_FIRST_ORDER, dev.to_dev(X[:T1]), dev.to_dev(U[:T1]), None, dev.to_dev(du1, dev.F32))
+        xp = np.vstack([X[:T1], X[T1 - 1:T1]])
+        _, B1, c1 = orc.first_order_B_decoupled(sys_o, xp, U[:T1], du1.astype(np.float64))
+        assert int(o["info"].abs().sum().item()) == 0
+        np.testing.assert_allclose(o["Bt"].cpu().numpy(), B1, rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(o["ct"].cpu().numpy(), c1, rtol=1e-4, atol=2e-5)
