@@ -420,11 +420,13 @@ def main():
                          "reference's semantics) or 50 over-relaxed projected sweeps + polish")
     ap.add_argument("--no-graph", action="store_true",
                     help="several ranks: issue the step's launches one by one instead of replaying a HIP graph")
-    ap.add_argument("--collective", default="auto", choices=["auto", "torch", "direct"],
+    ap.add_argument("--collective", default="auto", choices=["auto", "torch", "direct", "peer"],
                     help="several ranks: the all-reduce issued by the HIP library on an RCCL communicator it owns, "
                          "the whole step captured into a HIP graph inside the library (csrc/collective.hip; 'direct'), "
                          "or through torch.distributed ('torch').  'auto' (default) = direct whenever the backend is "
-                         "nccl and every rank can bind RCCL and join the communicator, else torch")
+                         "nccl and every rank can bind RCCL and join the communicator, else torch.  'peer' (opt-in, "
+                         "not yet validated on several physical GPUs): no collective library at all -- every rank "
+                         "reads the other ranks' statistics out of IPC-mapped device memory in one small launch")
     ap.add_argument("--force-unfused", action="store_true",
                     help="one GPU: time the multi-GPU step (accumulate + all-reduce + solve) with a 1-rank RCCL group")
     args = ap.parse_args()
@@ -505,6 +507,7 @@ def main():
             args.collective, step_info["collective_fallback"] = "torch", why
 
     stream = torch.cuda.current_stream().cuda_stream
+    peers = []                  # --collective peer: the exchanges made (one per timed workload), destroyed at the end
 
     def barrier():
         if world > 1:
@@ -577,11 +580,15 @@ def main():
 
             def smooth_step():
                 plan.run(stream)
-        elif args.collective == "direct":
-            # the library issues accumulate -> RCCL all-reduce -> solve itself and replays them as one HIP graph
-            from irs_mpc_amd.distributed import CollectiveStep
+        elif args.collective in ("direct", "peer"):
+            # the library issues accumulate -> all-reduce (RCCL, or the IPC peer exchange) -> solve itself and
+            # replays them as one HIP graph
+            from irs_mpc_amd.distributed import CollectiveStep, PeerExchange
             plan = dev.SmoothPlan(dm, MODE, x_trj, u_trj, dx=dx, du=du, fuse=True, n_total=n_total)
             tv = plan.out
+            if args.collective == "peer":
+                step_info["comm"] = PeerExchange(plan.sums.numel())
+                peers.append(step_info["comm"])
             cstep = CollectiveStep(plan, step_info["comm"])
             cstep.run()
             torch.cuda.synchronize()
@@ -591,7 +598,10 @@ def main():
             torch.cuda.synchronize()
             assert all(torch.equal(a_, tv[k]) for a_, k in zip(ref, ("At", "Bt", "ct"))), "replayed step differs"
             step_info["graph"] = True
-            step_info["collective"] = "direct (library-owned RCCL communicator, graph captured in the library)"
+            step_info["collective"] = ("direct (library-owned RCCL communicator, graph captured in the library)"
+                                       if args.collective == "direct" else
+                                       "peer (IPC-mapped exchange regions, one launch, no collective library; graph "
+                                       "captured in the library)")
             smooth_step = cstep.run
         else:
             plan = dev.SmoothPlan(dm, MODE, x_trj, u_trj, dx=dx, du=du, fuse=False, n_total=n_total)
@@ -705,7 +715,9 @@ def main():
                     if not unfused:
                         At_, Bt_, ct_ = lplan.out["At"], lplan.out["Bt"], lplan.out["ct"]
                     else:
-                        if args.force_unfused:
+                        if args.collective == "peer":
+                            step_info["comm"].all_reduce_sums(lplan.sums)
+                        elif args.force_unfused:
                             dist.all_reduce(lplan.sums)
                         else:
                             all_reduce_sums(lplan.sums)
@@ -990,6 +1002,10 @@ def main():
         if hasattr(lib, "irs_cbm_print_stamps"):
             lib.irs_cbm_print_stamps.restype = None
             lib.irs_cbm_print_stamps()
+    for px in peers:
+        step_info_t = px.status()
+        assert step_info_t[1] == 0, "peer exchange: %d of %d launches timed out waiting for a rank" % (step_info_t[1], step_info_t[0])
+        px.destroy()
     if world > 1 or args.force_unfused:
         dist.destroy_process_group()
 

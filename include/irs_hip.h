@@ -530,6 +530,29 @@ int irs_step_graph_create(const irs_smooth_call *call, void *comm, void *stream,
 int irs_step_graph_launch(void *graph_exec, void *stream);
 int irs_step_graph_destroy(void *graph_exec);
 
+/* ---- the same step with the exchange done WITHOUT a collective library (csrc/collective.hip; opt-in) ----------
+ * Replaces the same ZeroMQ fan-in as above.  Every rank publishes its (T,P) statistics in an exchange region of
+ * its own device memory and reads the other ranks' regions, mapped by IPC handle, directly over xGMI: one small
+ * launch between the sample pass and the solve (publish with system-scope stores -> release the step flag -> wait,
+ * bounded, for every rank's flag -> sum the blocks in RANK ORDER: the same bits on every rank).  Two alternating
+ * slots per region; a peer that does not arrive within IRS_PEER_TIMEOUT_MS (default 2000) poisons the statistics
+ * (NaN), which the solve reports through `info` -- the job fails, the GPU does not hang.
+ *   irs_peer_alloc       `region` = device memory for `count` doubles per slot (zeroed), `handle64` = its 64-byte
+ *                        IPC handle; the host gathers the handles of all ranks (any rendezvous)
+ *   irs_peer_create      maps the other ranks' regions; handles = nranks x 64 bytes in rank order (own entry unused)
+ *   irs_peer_allreduce_sums   the exchange launch alone: `sums` (count doubles) in place
+ *   irs_smooth_step_peer / irs_step_graph_create_peer   as irs_smooth_step_collective / irs_step_graph_create
+ *   irs_peer_status      launches and timeouts so far (synchronising read)
+ *   irs_peer_destroy     unmaps, frees the counters and, if given, the region (call on every rank after a barrier)
+ * Every rank must issue the same sequence of exchange launches.  Not yet run on more than one physical GPU. */
+int irs_peer_alloc(size_t count, void **region, void *handle64);
+int irs_peer_create(int nranks, int rank, void *region, size_t count, const void *handles, void **peer);
+int irs_peer_destroy(void *peer, void *region);
+int irs_peer_status(void *peer, unsigned long long *launches, unsigned long long *timeouts);
+int irs_peer_allreduce_sums(void *peer, double *sums, size_t count, void *stream);
+int irs_smooth_step_peer(const irs_smooth_call *call, void *peer, void *stream);
+int irs_step_graph_create_peer(const irs_smooth_call *call, void *peer, void *stream, void **graph_exec);
+
 #ifdef __cplusplus
 }
 #endif

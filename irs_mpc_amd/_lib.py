@@ -155,6 +155,13 @@ SIGNATURES["irs_smooth_step_collective"] = (c_int, [POINTER(SmoothCall), c_void_
 SIGNATURES["irs_step_graph_create"] = (c_int, [POINTER(SmoothCall), c_void_p, c_void_p, POINTER(c_void_p)])
 SIGNATURES["irs_step_graph_launch"] = (c_int, [c_void_p, c_void_p])
 SIGNATURES["irs_step_graph_destroy"] = (c_int, [c_void_p])
+SIGNATURES["irs_peer_alloc"] = (c_int, [c_size_t, POINTER(c_void_p), c_void_p])
+SIGNATURES["irs_peer_create"] = (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p, POINTER(c_void_p)])
+SIGNATURES["irs_peer_destroy"] = (c_int, [c_void_p, c_void_p])
+SIGNATURES["irs_peer_status"] = (c_int, [c_void_p, POINTER(ctypes.c_ulonglong), POINTER(ctypes.c_ulonglong)])
+SIGNATURES["irs_peer_allreduce_sums"] = (c_int, [c_void_p, _dp, c_size_t, c_void_p])
+SIGNATURES["irs_smooth_step_peer"] = (c_int, [POINTER(SmoothCall), c_void_p, c_void_p])
+SIGNATURES["irs_step_graph_create_peer"] = (c_int, [POINTER(SmoothCall), c_void_p, c_void_p, POINTER(c_void_p)])
 
 _lib = None
 

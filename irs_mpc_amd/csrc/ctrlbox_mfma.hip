@@ -913,6 +913,9 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
             if (chg < 0 && stale_hi >= t0) {
                 // the rest has settled: sweep the skipped prefix once and test ITS multipliers
                 const int ph = stale_hi;
+#ifdef IRS_CBM_STAMPS
+                st_acc[14] += ph - t0 + 1;
+#endif
                 backward_sweep(ph, t0);
                 stale_hi = t0 - 1;
                 policy_rollout(t0, uu_, ph + 1);
@@ -922,6 +925,9 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
                 }
                 chg = wmax_i(chg);
                 rsync();
+#ifdef IRS_CBM_STAMPS
+                st_acc[15] += chg >= 0 ? 1 : 0;
+#endif
             }
             if (chg < 0) conv = true;
             else t_dirty = chg;
@@ -1116,6 +1122,7 @@ extern "C" void irs_cbm_print_stamps(void) {
                     "%lld tails; MPC loop %lld cyc; of backward: waiting for the prefetched step data %lld cyc\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
     fprintf(stderr, "[cbm stamps] backward step phases: head+6 MFMA %lld, gather %lld, inverse+gains %lld, 3 MFMA+stores %lld cyc\n",
             h[8], h[9], h[10], h[11]);
-    fprintf(stderr, "[cbm stamps] forward: %lld rollouts, %lld cyc inside their step loops\n", h[12], h[13]);
+    fprintf(stderr, "[cbm stamps] forward: %lld rollouts, %lld cyc inside their step loops; backward steps that re-swept a lazily skipped "
+                    "pinned head: %lld (%lld of those sweeps released a component)\n", h[12], h[13], h[14], h[15]);
 }
 #endif

@@ -99,6 +99,63 @@ class DirectComm:
             self.handle = None
 
 
+class PeerExchange:
+    """The all-reduce of the (T,P) sums WITHOUT a collective library (include/irs_hip.h, irs_peer_*): every rank
+    publishes its block in an exchange region of its own device memory and reads the other ranks' regions, mapped by
+    IPC handle, directly; the blocks are added in rank order, so every rank holds the same bits.  The 64-byte
+    handles travel through torch.distributed (any backend).  Opt-in: RCCL (`DirectComm`) stays the default until a
+    multi-GPU node has validated the exchange's memory model."""
+
+    def __init__(self, count, group=None):
+        import ctypes
+        from . import _lib
+        self.lib = _lib.load()
+        self.rank, self.world = rank_world()
+        self.count = int(count)
+        self.region = ctypes.c_void_p()
+        mine = (ctypes.c_char * 64)()
+        _lib.check(self.lib.irs_peer_alloc(self.count, ctypes.byref(self.region), ctypes.cast(mine, ctypes.c_void_p)),
+                   "irs_peer_alloc")
+        blob = bytes(mine)
+        if self.world > 1:
+            t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).clone()
+            on_dev = dist.get_backend(group) == "nccl"
+            if on_dev:
+                t = t.cuda()
+            parts = [torch.empty_like(t) for _ in range(self.world)]
+            dist.all_gather(parts, t, group=group)
+            blob = b"".join(bytes(p_.cpu().numpy().tobytes()) for p_ in parts)
+        self._handles = (ctypes.c_char * (64 * self.world)).from_buffer_copy(blob)
+        self.handle = ctypes.c_void_p()
+        _lib.check(self.lib.irs_peer_create(self.world, self.rank, self.region, self.count,
+                                            ctypes.cast(self._handles, ctypes.c_void_p), ctypes.byref(self.handle)),
+                   "irs_peer_create")
+        if self.world > 1:
+            dist.barrier(group=group)           # every rank has mapped every region before the first launch
+
+    def all_reduce_sums(self, sums):
+        from . import _lib
+        _lib.check(self.lib.irs_peer_allreduce_sums(self.handle, sums.data_ptr(), sums.numel(),
+                                                    torch.cuda.current_stream().cuda_stream), "irs_peer_allreduce_sums")
+        return sums
+
+    def status(self):
+        """(launches, timeouts) so far; synchronises."""
+        import ctypes
+        from . import _lib
+        a, b = ctypes.c_ulonglong(), ctypes.c_ulonglong()
+        _lib.check(self.lib.irs_peer_status(self.handle, ctypes.byref(a), ctypes.byref(b)), "irs_peer_status")
+        return int(a.value), int(b.value)
+
+    def destroy(self, group=None):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            torch.cuda.synchronize()
+            if self.world > 1:
+                dist.barrier(group=group)       # nobody unmaps while a peer may still read
+            self.lib.irs_peer_destroy(self.handle, self.region)
+            self.handle = None
+
+
 class CollectiveStep:
     """One multi-GPU smoothing step of a `SmoothPlan` built with fuse=True outputs AND sums (accumulate ->
     all-reduce -> solve), issued by the library: `run()` enqueues the three launches, `capture()` records them
@@ -116,17 +173,26 @@ class CollectiveStep:
     def _comm(self):
         return self.comm.handle if self.comm is not None else None
 
+    def _enqueue(self, st):
+        if isinstance(self.comm, PeerExchange):
+            self._check(self.lib.irs_smooth_step_peer(self._ref, self.comm.handle, st), "irs_smooth_step_peer")
+        else:
+            self._check(self.lib.irs_smooth_step_collective(self._ref, self._comm(), st), "irs_smooth_step_collective")
+
     def capture(self):
         import ctypes
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):              # warm-up on the capture stream (RCCL sets its channels up lazily)
-                self._check(self.lib.irs_smooth_step_collective(self._ref, self._comm(), side.cuda_stream),
-                            "irs_smooth_step_collective")
+                self._enqueue(side.cuda_stream)
             side.synchronize()
-            self._check(self.lib.irs_step_graph_create(self._ref, self._comm(), side.cuda_stream,
-                                                       ctypes.byref(self._graph)), "irs_step_graph_create")
+            if isinstance(self.comm, PeerExchange):
+                self._check(self.lib.irs_step_graph_create_peer(self._ref, self.comm.handle, side.cuda_stream,
+                                                                ctypes.byref(self._graph)), "irs_step_graph_create_peer")
+            else:
+                self._check(self.lib.irs_step_graph_create(self._ref, self._comm(), side.cuda_stream,
+                                                           ctypes.byref(self._graph)), "irs_step_graph_create")
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         return self
@@ -136,7 +202,7 @@ class CollectiveStep:
         if self._graph.value:
             self._check(self.lib.irs_step_graph_launch(self._graph, st), "irs_step_graph_launch")
         else:
-            self._check(self.lib.irs_smooth_step_collective(self._ref, self._comm(), st), "irs_smooth_step_collective")
+            self._enqueue(st)
         return self.plan.out
 
     def destroy(self):

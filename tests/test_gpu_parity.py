@@ -1208,6 +1208,80 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert "all-reduce" in out["config"]["step"]
 
 
+def test_peer_exchange_two_ranks_on_one_gpu():
+    """The all-reduce WITHOUT a collective library (csrc/collective.hip, irs_peer_*): two processes on this one GPU map
+    each other's exchange regions by IPC handle and run 300 exchange launches back to back (slot reuse) -- every rank
+    gets the rank-ordered total, bit for bit the closed form, and no wait times out.  (What this cannot show is the
+    memory model across two L2s: that needs a multi-GPU node; include/irs_hip.h says so.)"""
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", IRS_PEER_TIMEOUT_MS="5000")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "tests", "helpers", "peer_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    assert "PEER_EXCHANGE_OK world=2" in r.stdout
+
+
+def test_bench_two_ranks_peer_exchange_on_one_gpu():
+    """bench.py --collective peer: the whole N > 1 step (accumulate -> peer exchange -> solve, captured into a HIP
+    graph inside the library; the iLQR loop's all-reduce too) with two ranks on this one GPU."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", IRS_PEER_TIMEOUT_MS="5000")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29619", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "20", "--warmup", "3", "--rehearse-one-gpu", "--collective", "peer",
+           "--T", "12", "--N", "1500"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=560, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["N_total"] == 3000 and out["value"] > 0
+    assert out["config"]["collective"].startswith("peer") and "one HIP graph" in out["config"]["step"]
+
+
+def test_peer_exchange_one_rank_step_equals_the_two_stage_path(amd):
+    """One rank: accumulate -> exchange launch -> solve (eager, and replayed from the library's HIP graph) == the
+    two-stage path, bit for bit (as test_collective_step_inside_the_library for the RCCL step); the counters count."""
+    from irs_mpc_amd import device as dev
+    from irs_mpc_amd.distributed import CollectiveStep, PeerExchange
+    from irs_mpc_amd._lib import SMOOTH_ZERO_ORDER_B
+    T, N = 6, 3000
+    sys_d, sys_o, x0, u_trj = _hand_setup(amd, T)
+    x_trj = orc.rollout(sys_o, x0, u_trj)
+    du = (0.1 * np.random.default_rng(3).normal(size=(T, N, 4))).astype(np.float32)
+    dm = sys_d.dm()
+    xd, ud, dud = dev.to_dev(x_trj), dev.to_dev(u_trj), dev.to_dev(du, dev.F32)
+    sums = dm.smooth_accumulate(SMOOTH_ZERO_ORDER_B, xd, ud, None, dud).clone()
+    ws = dm._workspace(SMOOTH_ZERO_ORDER_B, T, N, xd.device)
+    A0, B0, c0, i0 = [t.clone() for t in dm.smooth_finalize(SMOOTH_ZERO_ORDER_B, N, xd, ud, sums, workspace=ws)]
+    plan = dev.SmoothPlan(dm, SMOOTH_ZERO_ORDER_B, xd, ud, dx=None, du=dud, fuse=True, n_total=N)
+    px = PeerExchange(plan.sums.numel())
+    assert px.world == 1 and px.handle.value
+    step = CollectiveStep(plan, px)
+    for label in ("eager", "graph"):
+        for k in ("At", "Bt", "ct"):
+            plan.out[k].zero_()
+        if label == "graph":
+            step.capture()
+        o = step.run()
+        torch.cuda.synchronize()
+        assert torch.equal(o["Bt"], B0) and torch.equal(o["ct"], c0) and torch.equal(o["At"], A0), label
+        assert torch.equal(plan.sums, sums), label
+        assert int(o["info"].abs().sum().item()) == 0
+    s2 = sums.clone()
+    px.all_reduce_sums(s2)
+    torch.cuda.synchronize()
+    assert torch.equal(s2, sums)
+    launches, timeouts = px.status()
+    assert timeouts == 0 and launches == 5, (launches, timeouts)      # eager, 2 warm-ups of the capture, replay, bare
+    step.destroy()
+    px.destroy()
+
+
 def test_planar_hand_descent_runs(amd):
     """smooth -> Riccati -> closed-loop rollout through the contact functor in f64 == oracle."""
     from irs_mpc_amd import device as dev

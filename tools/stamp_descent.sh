@@ -13,3 +13,4 @@ cd $R
 IRS_HIP_LIB=$R/gpurun_out/libirs_hip_stamps.so python tools/time_quasistatic.py "$@" --stamps
 # ... and the LAST descent of the benchmark's iLQR loop (a warm-started one, late in an episode)
 IRS_PRINT_STAMPS=1 IRS_HIP_LIB=$R/gpurun_out/libirs_hip_stamps.so python bench.py --no-cpu-baseline --no-secondary --steps 200 --warmup 20 > /dev/null
+[ -n "$LOOP_PROFILE" ] && IRS_HIP_LIB=$R/gpurun_out/libirs_hip_stamps.so python tools/descent_loop_profile.py "$1" --stamps
