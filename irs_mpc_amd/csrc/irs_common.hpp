@@ -8,6 +8,12 @@
 
 void irs_set_error(const char* fmt, ...);
 
+// tvlqr.hip, for iterate.hip: irs_tvlqr_descent whose launch also writes the fused iterate's info row (row may be null)
+int irs_tvlqr_descent_row(int model, const double* params, int n_params, int T, const double* At, const double* Bt,
+                          const double* ct, const double* Q, const double* Qd, const double* R, double alpha_R,
+                          const double* xd_trj, const double* x0, double* K, double* k, double* x_new, double* u_new,
+                          double* cost, int* info, const int* smooth_info, int* row, void* stream);
+
 #define IRS_CHECK_ARG(cond, msg)                               \
     do {                                                       \
         if (!(cond)) {                                         \

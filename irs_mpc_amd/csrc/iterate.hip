@@ -81,27 +81,8 @@ __global__ void plan_check_kernel(int n, int m, int T, const double* __restrict_
 }
 
 // row of the iteration's info history: [0] Riccati info, [1] timesteps whose smoothing solve failed, [2] box needed,
-// [3..5] the bounded descent's info (valid when [2] != 0), [6] box needed but the horizon does not fit its kernel
-__global__ void iterate_info_kernel(const int* descent_info, const int* smooth_info, int T, const int* box_flag,
-                                    const int* box_info, int box_unsupported, int* row) {
-    int bad = 0;
-    if (smooth_info != nullptr)
-        for (int t = threadIdx.x; t < T; t += 64) bad += smooth_info[t] != 0 ? 1 : 0;
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) bad += __shfl_xor(bad, s, 64);
-    if (threadIdx.x == 0) {
-        const int need = box_flag != nullptr ? *box_flag : 0;
-        row[0] = descent_info[0];
-        row[1] = bad;
-        row[2] = need;
-        row[3] = (need && box_info) ? box_info[0] : 0;
-        row[4] = (need && box_info) ? box_info[1] : 0;
-        row[5] = (need && box_info) ? box_info[2] : 0;
-        row[6] = need && box_unsupported ? 1 : 0;
-        row[7] = 0;
-    }
-}
-
+// [3..5] the bounded descent's info (valid when [2] != 0), [6] box needed but the horizon does not fit its kernel.
+// Written by plan_check_kernel (bounds given) or by the descent's own launch (no bounds: tvlqr.hip, descent_kernel).
 struct PhaseTimer {
     bool on;
     hipStream_t st;
@@ -218,8 +199,10 @@ int irs_iterate(const irs_iterate_call* c, irs_timing* timing, void* stream) {
         }
         if (rc != IRS_OK) return rc;
         tm.mark(1);
-        rc = irs_tvlqr_descent(c->model, c->params, c->n_params, T, At, Bt, ct, c->Q, c->Qd, c->R, c->alpha_R, c->xd_trj,
-                               x_nom, K, k, x_new, u_new, c->cost_hist + it, descent_info, stream);
+        // (no bounds: the descent's own launch writes the row of the info history)
+        rc = irs_tvlqr_descent_row(c->model, c->params, c->n_params, T, At, Bt, ct, c->Q, c->Qd, c->R, c->alpha_R,
+                                   c->xd_trj, x_nom, K, k, x_new, u_new, c->cost_hist + it, descent_info,
+                                   exact ? nullptr : smooth_info, bounded ? nullptr : c->info_hist + (size_t)it * 8, stream);
         if (rc != IRS_OK) return rc;
         tm.mark(2);
         if (bounded) {
@@ -236,9 +219,6 @@ int irs_iterate(const irs_iterate_call* c, irs_timing* timing, void* stream) {
                                               stream);       // its info lands in the row (zeroed above) if it runs
                 if (rc != IRS_OK) return rc;
             }
-        } else {
-            hipLaunchKernelGGL(iterate_info_kernel, dim3(1), dim3(64), 0, st, descent_info, exact ? nullptr : smooth_info, T,
-                               nullptr, nullptr, 0, c->info_hist + (size_t)it * 8);
         }
         tm.mark(3);
         tm.collect();

@@ -1033,7 +1033,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(ModelParams p, int T, const
 // rollout of the policy it just wrote.
 template <class Model>
 __global__ __launch_bounds__(64) void descent_kernel(ModelParams p, RiccatiArgs a, const double* x0,
-                                                     double* x_new, double* u_new, double* cost_out) {
+                                                     double* x_new, double* u_new, double* cost_out,
+                                                     const int* smooth_info, int* row) {
     __shared__ RiccatiLds<Model::NX, Model::NU> S;
     __shared__ RolloutLds<Model> S2;
     const int lane = threadIdx.x;
@@ -1043,6 +1044,21 @@ __global__ __launch_bounds__(64) void descent_kernel(ModelParams p, RiccatiArgs 
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     rollout_device<Model>(p, a.T, a.K, a.k, nullptr, x0, a.Q, a.R, a.xd, x_new, u_new, cost_out, lane, S2);
+    // fused iterate (iterate.hip), no bounds: this descent's row of the info history -- [0] Riccati info,
+    // [1] timesteps whose smoothing solve failed, the rest zero -- without a launch of its own
+    if (row != nullptr) {
+        int bad = 0;
+        if (smooth_info != nullptr)
+            for (int t = lane; t < a.T; t += 64) bad += smooth_info[t] != 0 ? 1 : 0;
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) bad += __shfl_xor(bad, sft, 64);
+        if (lane == 0) {
+            row[0] = a.info[0];
+            row[1] = bad;
+#pragma unroll
+            for (int i = 2; i < 8; ++i) row[i] = 0;
+        }
+    }
 }
 
 // evaluate_cost of a given trajectory pair: lanes stride over t, f64 wave reduction.
@@ -1255,6 +1271,18 @@ int irs_tvlqr_descent(int model, const double* params, int n_params, int T, cons
                       const double* R, double alpha_R, const double* xd_trj, const double* x0,
                       double* K, double* k, double* x_new, double* u_new, double* cost, int* info,
                       void* stream) {
+    return irs_tvlqr_descent_row(model, params, n_params, T, At, Bt, ct, Q, Qd, R, alpha_R, xd_trj, x0, K, k, x_new,
+                                 u_new, cost, info, nullptr, nullptr, stream);
+}
+
+}  // extern "C"
+
+// irs_tvlqr_descent + (row != null) the 8-int info row of the fused iterate, written by the same launch
+int irs_tvlqr_descent_row(int model, const double* params, int n_params, int T, const double* At,
+                          const double* Bt, const double* ct, const double* Q, const double* Qd,
+                          const double* R, double alpha_R, const double* xd_trj, const double* x0,
+                          double* K, double* k, double* x_new, double* u_new, double* cost, int* info,
+                          const int* smooth_info, int* row, void* stream) {
     IRS_CHECK_ARG(T > 0 && At && Bt && ct && Q && Qd && R && xd_trj && x0 && K && k && x_new && u_new &&
                   cost && info, "bad argument");
     ModelParams p;
@@ -1263,10 +1291,9 @@ int irs_tvlqr_descent(int model, const double* params, int n_params, int T, cons
     hipStream_t st = static_cast<hipStream_t>(stream);
     IRS_DISPATCH_MODEL(model, {
         RiccatiArgs a{At, Bt, ct, Q, Qd, R, xd_trj, K, k, info, alpha_R, Model::NX, Model::NU, T};
-        hipLaunchKernelGGL((descent_kernel<Model>), dim3(1), dim3(64), 0, st, p, a, x0, x_new, u_new, cost);
+        hipLaunchKernelGGL((descent_kernel<Model>), dim3(1), dim3(64), 0, st, p, a, x0, x_new, u_new, cost, smooth_info,
+                           row);
     });
     IRS_CHECK_LAUNCH();
     return IRS_OK;
 }
-
-}  // extern "C"
