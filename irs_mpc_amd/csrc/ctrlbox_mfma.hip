@@ -135,7 +135,7 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
     // diagnostic build only (-DIRS_CBM_STAMPS, tools/stamp_descent.sh): cycle totals per phase of the solver
     // wave -> stamps[]; in the product build no stamp executes (stamps == nullptr, code compiled out)
 #ifdef IRS_CBM_STAMPS
-    long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long st_acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define CBM_MARK(k) do { const long long st_now = __builtin_amdgcn_s_memtime(); st_acc[k] += st_now - st_mark; st_mark = st_now; } while (0)
 #define CBM_T0() const long long st_t0 = __builtin_amdgcn_s_memtime()
 #define CBM_ADD(k, n) do { st_acc[k] += __builtin_amdgcn_s_memtime() - st_t0; st_acc[(k) + 1] += (n); } while (0)
@@ -935,6 +935,10 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
         if (stale_hi >= t0) { t_dirty = max(t_dirty, stale_hi); stale_hi = t0 - 1; }      // phase 2 sweeps everything dirty
         // ---- phase 2: primal active set from the clipped iterate
         if (!conv) {
+#ifdef IRS_CBM_STAMPS
+            st_acc[16] += 1;
+            st_acc[18] += iters;
+#endif
             int chg = -1;
             for (int q = t0 * M + lane; q < T * M; q += 64) {
                 const double lo = lo_[q], hi = hi_[q];
@@ -1002,6 +1006,9 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
                 }
             }
         }
+#ifdef IRS_CBM_STAMPS
+        st_acc[17] += iters;
+#endif
         it_max = max(it_max, iters);
         n_fail += conv ? 0 : 1;
         full = !conv;
@@ -1021,7 +1028,7 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
 #ifdef IRS_CBM_STAMPS
     if (lane == 0 && stamps != nullptr) {
         st_acc[6] = __builtin_amdgcn_s_memtime() - st_begin;
-        for (int k = 0; k < 16; ++k) stamps[k] = st_acc[k];
+        for (int k = 0; k < 24; ++k) stamps[k] = st_acc[k];
     }
 #endif
 }
@@ -1033,8 +1040,8 @@ constexpr size_t kLdsMax = 160 * 1024 - 512;
 static long long* g_stamps = nullptr;
 static long long* cbm_stamps() {
     if (g_stamps == nullptr) {
-        (void)hipMalloc(reinterpret_cast<void**>(&g_stamps), 16 * sizeof(long long));
-        (void)hipMemset(g_stamps, 0, 16 * sizeof(long long));
+        (void)hipMalloc(reinterpret_cast<void**>(&g_stamps), 24 * sizeof(long long));
+        (void)hipMemset(g_stamps, 0, 24 * sizeof(long long));
     }
     return g_stamps;
 }
@@ -1115,7 +1122,7 @@ int irs_ctrlbox_mfma_launch(int model, const BoxArgs& a, int kind, double* ws, s
 #ifdef IRS_CBM_STAMPS
 // diagnostic build only: cycle totals of the LAST launch's solver wave
 extern "C" void irs_cbm_print_stamps(void) {
-    long long h[16];
+    long long h[24];
     (void)hipDeviceSynchronize();
     if (g_stamps == nullptr || hipMemcpy(h, g_stamps, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
     fprintf(stderr, "[cbm stamps] backward %lld cyc / %lld steps; forward %lld cyc / %lld steps; wait for plant %lld cyc / "
@@ -1124,5 +1131,7 @@ extern "C" void irs_cbm_print_stamps(void) {
             h[8], h[9], h[10], h[11]);
     fprintf(stderr, "[cbm stamps] forward: %lld rollouts, %lld cyc inside their step loops; backward steps that re-swept a lazily skipped "
                     "pinned head: %lld (%lld of those sweeps released a component)\n", h[12], h[13], h[14], h[15]);
+    fprintf(stderr, "[cbm stamps] active-set iterations over all tails: %lld; tails that left the primal-dual phase unconverged: %lld "
+                    "(after %lld iterations)\n", h[17], h[16], h[18]);
 }
 #endif

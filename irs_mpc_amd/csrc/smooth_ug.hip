@@ -492,7 +492,7 @@ __device__ __forceinline__ void ug_nominal(const SmoothArgs& a, const UgUni<Mode
 }
 
 // -DIRS_UG_STAMPS (tuning builds only): s_memtime at the phase boundaries of every workgroup -> a device buffer that
-// irs_debug_ug_stamps copies out (tools/ug_stamps.py)
+// irs_debug_ug_stamps copies out (tests/tools/ug_stamps.py)
 #ifdef IRS_UG_STAMPS
 constexpr int kUgStampSlots = 12, kUgStampWgs = 2048;
 __device__ unsigned long long ug_stamps[kUgStampWgs * kUgStampSlots];

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # the stated fp32 tolerance of the sample pass against the f64 oracle on identical samples;
-# measured on the device: ~1e-6 for the analytic AND the contact models (tools/contact_tolerance_probe.py)
+# measured on the device: ~1e-6 for the analytic AND the contact models (tests/tools/contact_tolerance_probe.py)
 FP32_TOL = dict(rtol=1e-4, atol=2e-5)
 
 

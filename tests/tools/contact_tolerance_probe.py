@@ -1,11 +1,11 @@
 """Prints the actual device-vs-oracle errors of the contact sample pass (the quantities the parity tests and
-smoke() bound), so that their tolerances can be set from measurements:   python tools/contact_tolerance_probe.py"""
+smoke() bound), so that their tolerances can be set from measurements:   python tests/tools/contact_tolerance_probe.py"""
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import irs_mpc_amd as amd  # noqa: E402
 from irs_mpc_amd import device as dev  # noqa: E402
 from irs_mpc_amd._lib import SMOOTH_FIRST_ORDER, SMOOTH_ZERO_ORDER_B  # noqa: E402

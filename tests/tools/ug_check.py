@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Uniform-geometry sample pass (csrc/smooth_ug.hip) against the general kernel (IRS_UG=0) and the oracle, and
-timed: python tools/ug_check.py [N]"""
+timed: python tests/tools/ug_check.py [N]"""
 import os
 import sys
 import time
@@ -8,7 +8,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import irs_mpc_amd as amd  # noqa: E402
 from irs_mpc_amd import device as dev  # noqa: E402
 from irs_mpc_amd._lib import SMOOTH_FIRST_ORDER, SMOOTH_ZERO_ORDER_B  # noqa: E402

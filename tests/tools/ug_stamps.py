@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Phase stamps of the uniform-geometry kernel (a -DIRS_UG_STAMPS build of csrc/smooth_ug.hip, tools/ug_variants.sh):
 per workgroup, s_memtime at start / geometry done / table done / sample loop done / statistics ready / end, and the
-nominal wave's finish.  python tools/ug_stamps.py [N]"""
+nominal wave's finish.  python tests/tools/ug_stamps.py [N]"""
 import ctypes
 import os
 import sys
@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import irs_mpc_amd as amd  # noqa: E402
 from irs_mpc_amd import _lib, device as dev  # noqa: E402
 from irs_mpc_amd._lib import SMOOTH_ZERO_ORDER_B  # noqa: E402

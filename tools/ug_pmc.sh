@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes (one counter per run) over tools/ug_time.py for the uniform-geometry kernel: tools/ug_pmc.sh TAG N
+# PMC passes (one counter per run) over tests/tools/ug_time.py for the uniform-geometry kernel: tools/ug_pmc.sh TAG N
 TAG=${1:-ug}
 N=${2:-100000}
 R=$GRAFT_REPO_ROOT
@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for C in SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA; do
-  timeout -k 10 120 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -- python3 $R/tools/ug_time.py --zero $N > $OUT/$C.log 2>&1
+  timeout -k 10 120 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -- python3 $R/tests/tools/ug_time.py --zero $N > $OUT/$C.log 2>&1
   echo "$C rc=$?"
 done
 cd $R

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Builds variants of the uniform-geometry kernel for tuning runs: tools/ug_variants.sh TAG "-DIRS_UG_SWEEPS=4 ..." [TAG FLAGS]...
 # -> irs_mpc_amd/csrc/variants/libirs_hip_TAG.so (git-ignored; travels to the GPU box).  On the box:
-#    for v in irs_mpc_amd/csrc/variants/*.so; do cp $v irs_mpc_amd/csrc/libirs_hip.so; python tools/ug_time.py ...; done
+#    for v in irs_mpc_amd/csrc/variants/*.so; do cp $v irs_mpc_amd/csrc/libirs_hip.so; python tests/tools/ug_time.py ...; done
 set -e
 cd $(dirname $0)/../irs_mpc_amd/csrc
 mkdir -p variants
