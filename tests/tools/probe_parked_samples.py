@@ -1,6 +1,6 @@
 """Diagnostic: the sample pass of the exact contact models (parked samples, smooth.hip DEFER) against the per-sample
 lanes of irs_contact_samples_f32 at several N -- run on the GPU box:  gpurun -- python tests/tools/probe_parked_samples.py"""
-import sys, numpy as np, torch
+import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import irs_mpc_amd as amd
 from irs_mpc_amd import device as dev
