@@ -43,6 +43,16 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) double* gptr_d;
 
 constexpr int kPdasIterM = 10;
+// Primal-dual iterations that did not settle in kPdasIterM rounds are CYCLING (rate-limited problems: a component
+// released from one bound shoots past the other one in the next round, and a whole bang-bang stretch flips with it).
+// Before falling back to the primal method -- one constraint per iteration: 50-140 iterations for such a tail, each a
+// sweep of up to the whole horizon; 3 of 80 tails like that were two thirds of a box-pivoting descent -- the
+// iteration goes on with a damped rule: every violated bound is still pinned at once, but only the ONE pinned
+// component with the worst multiplier is released per round.  Measured on the benchmark's box-pivoting loop (oracle
+// twin on inputs dumped from the device, tests/tools/pdas_study.py): backward steps of the descents that used to fall
+// back 13 641 -> 4 880, 10 210 -> 1 900, 24 122 -> 15 150; descents that never cycled are unchanged.  The QP is
+// strictly convex: whichever rule finds the optimal set finds the same solution.
+constexpr int kPdasSingleM = 50;
 #ifndef IRS_LAZY_MIN
 #define IRS_LAZY_MIN 6
 #endif
@@ -875,8 +885,9 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
             }
             return pe;
         };
-        for (int it = 0; it < kPdasIterM && !conv; ++it) {
+        for (int it = 0; it < kPdasIterM + kPdasSingleM && !conv; ++it) {
             ++iters;
+            const bool single = it >= kPdasIterM;          // release the worst pinned component only
             // (a short run is not worth an extra rollout and a later release: measured on the rate-limited box
             // problem, where skipping 1-3 steps cost more iterations than it saved sweeps)
             int pe = t0 - 1;
@@ -894,6 +905,8 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
             }
             policy_rollout(t0, uu_, T);
             int chg = -1;
+            double rworst = 0.0;
+            int rq = 0x7fffffff;
             for (int q = t0 * M + lane; q < T * M; q += 64) {
                 const double ac = act_[q], u = uu_[q], mu = mu_[q];
                 const bool fresh = q / M > stale_hi;   // multipliers of the skipped prefix are not current
@@ -906,7 +919,20 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
                 } else {
                     if (fresh && mu > tol) nw = 0.0;
                 }
+                if (single && nw == 0.0 && ac != 0.0) {     // a release: remembered, not applied
+                    const double v = fabs(mu);
+                    if (v > rworst) { rworst = v; rq = q; }
+                    nw = ac;
+                }
                 if (nw != ac) { act_[q] = nw; bnd_[q] = nw < 0.0 ? lo_[q] : hi_[q]; sig_[q / M] = -1.0; chg = max(chg, q / M); }
+            }
+            if (single) {
+                const double wm = wmax_d(rworst);
+                if (wm > 0.0) {
+                    const int qw = wmin_i(rworst == wm ? rq : 0x7fffffff);      // first index among equals
+                    if (lane == 0) { act_[qw] = 0.0; sig_[qw / M] = -1.0; }
+                    chg = max(chg, qw / M);
+                }
             }
             chg = wmax_i(chg);
             rsync();

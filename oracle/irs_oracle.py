@@ -1535,14 +1535,18 @@ def ctrlbox_backward(prob, act, lo, hi, t_hi, t_lo, W):
         W["K"][t], W["k"][t], W["H"][t], W["G"][t], W["g"][t] = K, k, H, G, g
 
 
-def ctrlbox_solve(prob, s_start, t0, lo, hi, u, act, W, valid_from, pdas_iter=10, max_iter=2000, tol=1e-10):
+def ctrlbox_solve(prob, s_start, t0, lo, hi, u, act, W, valid_from, pdas_iter=10, max_iter=2000, tol=1e-10,
+                  single_iter=50):
     """Active-set solve of the tail t0..T-1 from s_start.  `act` (T,m) in {-1 at lo, 0 free, +1 at hi}
     is the warm start (updated in place), W the backward-pass cache valid for t >= valid_from
     (T = nothing valid), `u` (T,m) receives the solution.
       phase 1: primal-dual active-set iterations (Hintermueller-Ito-Kunisch): all violated bounds
                are pinned and all wrong-signed multipliers released at once; converges in a handful
                of iterations when it converges, but may cycle;
-      phase 2 (after pdas_iter iterations): classic primal active-set from the clipped iterate --
+      phase 1b (iterations pdas_iter+1 .. pdas_iter+single_iter, round 3; csrc/ctrlbox_mfma.hip kPdasSingleM): the
+               same with a damped release rule -- all violated bounds pinned, only the ONE pinned component with
+               the worst multiplier released -- which ends the cycles of rate-limited (bang-bang) tails;
+      phase 2 (after that): classic primal active-set from the clipped iterate --
                one constraint added (blocking step) or dropped (worst multiplier) per iteration;
                finite and monotone for a strictly convex QP.
     Every iteration is a partial backward sweep (from the latest changed time step) plus vector
@@ -1569,15 +1573,19 @@ def ctrlbox_solve(prob, s_start, t0, lo, hi, u, act, W, valid_from, pdas_iter=10
 
     t_dirty = T - 1 if valid_from >= T else (valid_from - 1 if valid_from > t0 else t0 - 1)
     # ---- phase 1: primal-dual active set
-    for it in range(1, pdas_iter + 1):
+    for it in range(1, pdas_iter + single_iter + 1):
         backward(t_dirty)
         policy_rollout(u)
         a, uu, mm = act[t0:], u[t0:], mu[t0:]
         new = a.copy()
         new[(a == 0) & (uu < lo[t0:] - tol)] = -1
         new[(a == 0) & (uu > hi[t0:] + tol)] = 1
-        new[(a < 0) & (mm < -tol)] = 0
-        new[(a > 0) & (mm > tol)] = 0
+        rel = ((a < 0) & (mm < -tol)) | ((a > 0) & (mm > tol))
+        if it > pdas_iter and rel.any():
+            worst = np.unravel_index(np.argmax(np.where(rel, np.abs(mm), 0.0)), rel.shape)
+            rel = np.zeros_like(rel)
+            rel[worst] = True
+        new[rel] = 0
         changed = np.nonzero((new != a).any(axis=1))[0]
         if changed.size == 0:
             return s, u, mu, (it, 0, swept), t0
@@ -1611,11 +1619,11 @@ def ctrlbox_solve(prob, s_start, t0, lo, hi, u, act, W, valid_from, pdas_iter=10
         u[t0:] = us[t0:]
         viol = np.where(act[t0:] < 0, -mu[t0:], np.where(act[t0:] > 0, mu[t0:], 0.0))   # > 0 = wrong sign
         if viol.max() <= tol:
-            return s, u, mu, (pdas_iter, it2, swept), t0
+            return s, u, mu, (pdas_iter + single_iter, it2, swept), t0
         r, j = np.unravel_index(np.argmax(viol), viol.shape)
         act[t0 + r, j] = 0
         t_dirty = t0 + r
-    return s, u, mu, (pdas_iter, -max_iter, swept), t0
+    return s, u, mu, (pdas_iter + single_iter, -max_iter, swept), t0
 
 
 def ctrlbox_workspace(prob):

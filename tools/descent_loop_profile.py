@@ -1,6 +1,6 @@
 """Per-iteration cost of the bounded descent inside the bench's 20-iteration planar-hand (or box-pivoting) loop.
 
-    gpurun -- python tools/descent_loop_profile.py [planar_hand|box_pivoting] [--stamps]
+    gpurun -- python tools/descent_loop_profile.py [planar_hand|box_pivoting] [--stamps] [--dump=K ...]
 
 Replays bench.py's episode (fresh device-drawn samples, bounds re-centred, first tail's active set handed on) with a
 synchronisation after every descent: ms per descent, info, cost; with the diagnostic library of tools/stamp_descent.sh
@@ -19,6 +19,7 @@ from irs_mpc_amd import _lib, device as dev  # noqa: E402
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "planar_hand"
     stamps = "--stamps" in sys.argv
+    dump = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--dump=")]      # iterations whose inputs to save
     w = bench.Workload(name)
     N = 10000 if name == "planar_hand" else 6250
     dm = w.system.dm()
@@ -57,6 +58,12 @@ def main():
             plan.run()
             br = bound_rows(xs[a_])
             torch.cuda.synchronize()
+            if ep == 1 and it in dump:
+                import numpy as np
+                np.savez(os.path.join("gpurun_out", "descent_inputs_%s_it%d.npz" % (name, it)),
+                         At=plan.out["At"].cpu().numpy(), Bt=plan.out["Bt"].cpu().numpy(), ct=plan.out["ct"].cpu().numpy(),
+                         Q=w.Q, Qd=w.Qd, R=w.R, xd=w.xd, x0=w.x0, act=act.cpu().numpy(), kind=kind,
+                         **{k_: v_.cpu().numpy() for k_, v_ in br.items()})
             t0 = time.perf_counter()
             louts[b_] = dm.quasistatic_box_descent(plan.out["At"], plan.out["Bt"], plan.out["ct"], Q, Qd, R, xd, x0,
                                                    solver=0, max_iter=2000, eps=1e-9, out=louts[b_], act=act, **br)
