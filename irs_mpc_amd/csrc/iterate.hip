@@ -80,6 +80,172 @@ __global__ void plan_check_kernel(int n, int m, int T, const double* __restrict_
     }
 }
 
+// lane N of every 16-lane row to all lanes of that row (DPP row_newbcast, as in ctrlbox_mfma.hip)
+template <int N>
+__device__ __forceinline__ double pc_row_bcast(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + N, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + N, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// one unrolled step of the walk: x_l to its 16-lane group by DPP, two partial sums per output (half the FMA chain)
+template <int NN, int l = 0>
+struct PcWalk {
+    static __device__ __forceinline__ void run(const double* a_r, const double* k_r, double x, double* ax, double* au) {
+        const double xl = pc_row_bcast<l>(x);
+        ax[l & 1] = fma(a_r[l], xl, ax[l & 1]);
+        au[l & 1] = fma(k_r[l], xl, au[l & 1]);
+        if constexpr (l + 1 < NN) PcWalk<NN, l + 1>::run(a_r, k_r, x, ax, au);
+    }
+};
+
+// The same test, fast: the serial kernel above walks every tail with ONE thread that fetches (A, B, K) from L2 step
+// by step -- 1.07 ms for the quadrotor (T = 50, n = 12), 50 us for the pendulum, per iteration, with the bounds the
+// reference's scripts pass.  Here one 1024-thread workgroup (a) forms the closed loop of every step ONCE,
+//     x+ = Acl_s x + bcl_s,  Acl_s = A_s + B_s K_s,  bcl_s = B_s k_s + c_s,
+// into LDS (transposed: lanes read consecutive words), then (b) walks all tails at once, 16 lanes per tail (lane i
+// owns x_i and row i; lanes < m also the control row): x_l reaches its group by one DPP move per word (a shuffle
+// through LDS is ~200 cycles of latency: twelve in a row per step made this 55 us), the state size is a template
+// parameter (every loop unrolled, no predication).
+template <int NN>
+__global__ __launch_bounds__(1024) void plan_check16_kernel(int m, int T, const double* __restrict__ At,
+                                                            const double* __restrict__ Bt, const double* __restrict__ ct,
+                                                            const double* __restrict__ K, const double* __restrict__ k,
+                                                            const double* __restrict__ x_new,
+                                                            const double* __restrict__ xlo, const double* __restrict__ xhi,
+                                                            const double* __restrict__ ulo, const double* __restrict__ uhi,
+                                                            int* flag, const int* descent_info, const int* smooth_info,
+                                                            int box_unsupported, int* row) {
+    constexpr int n = NN, L = 16;
+    extern __shared__ double psh[];
+    double* AclT = psh;                          // [s][l][i]
+    double* bcl = AclT + (size_t)T * n * n;      // [s][i]
+    double* KsT = bcl + (size_t)T * n;           // [s][l][j]
+    double* ks = KsT + (size_t)T * n * m;        // [s][j]
+    __shared__ int viol, nbad;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (tid == 0) { viol = 0; nbad = 0; }
+    for (int idx = tid; idx < T * n * n; idx += nt) {
+        const int s = idx / (n * n), r = idx - s * n * n, l = r / n, i = r - l * n;
+        double a = At[((size_t)s * n + i) * n + l];
+        for (int j = 0; j < m; ++j) a = fma(Bt[((size_t)s * n + i) * m + j], K[((size_t)s * m + j) * n + l], a);
+        AclT[idx] = a;
+    }
+    for (int idx = tid; idx < T * n; idx += nt) {
+        const int s = idx / n, i = idx - s * n;
+        double b = ct[idx];
+        for (int j = 0; j < m; ++j) b = fma(Bt[((size_t)s * n + i) * m + j], k[(size_t)s * m + j], b);
+        bcl[idx] = b;
+    }
+    for (int idx = tid; idx < T * n * m; idx += nt) {
+        const int s = idx / (n * m), r = idx - s * n * m, l = r / m, j = r - l * m;
+        KsT[idx] = K[((size_t)s * m + j) * n + l];
+    }
+    for (int idx = tid; idx < T * m; idx += nt) ks[idx] = k[idx];
+    __syncthreads();
+    const int G = nt / L, g = tid / L, i = tid % L;
+    const int ii = i < n ? i : 0, jj = i < m ? i : 0;       // lanes without a row recompute row 0 and discard it
+    const double lo_x = xlo[ii], hi_x = xhi[ii], lo_u = ulo[jj], hi_u = uhi[jj];
+    bool bad = false;
+    // every lane of a wave runs the same trip counts: a group without a tail walks the last one and discards
+    for (int tb = 0; tb < T; tb += G) {
+        const int t = tb + g;
+        const bool live = t < T;
+        const int tt = live ? t : T - 1;
+        // the four groups of a wave start at consecutive tails: walk from the wave's earliest
+        int s = tb + (tid / 64) * (64 / L);
+        s = s < T ? s : T - 1;
+        double x = i < n ? x_new[(size_t)tt * n + i] : 0.0;
+        double a_r[NN], k_r[NN], b_r, kk_r;
+        auto fetch = [&](int s_) {
+            const double* Ar = AclT + (size_t)s_ * n * n + ii;
+            const double* Kr = KsT + (size_t)s_ * n * m + jj;
+#pragma unroll
+            for (int l = 0; l < NN; ++l) { a_r[l] = Ar[l * n]; k_r[l] = Kr[l * m]; }
+            b_r = bcl[s_ * n + ii];
+            kk_r = ks[s_ * m + jj];
+        };
+        for (; s < T; ++s) {
+            // (no prefetch of the next step's rows: with 24 + 24 registers of operands in flight twice the kernel spills
+            // under the 128-register limit of a 1024-thread workgroup; three to four waves per SIMD hide the LDS latency)
+            fetch(s);
+            double ax[2] = {b_r, 0.0}, au[2] = {kk_r, 0.0};
+            PcWalk<NN>::run(a_r, k_r, x, ax, au);
+            const double xs = ax[0] + ax[1], us = au[0] + au[1];
+            if (s >= tt) {
+                bad = bad || (live && i < m && (us < lo_u || us > hi_u)) || (live && i < n && (xs < lo_x || xs > hi_x));
+                x = i < n ? xs : 0.0;
+            }
+        }
+    }
+    if (bad) viol = 1;
+    if (smooth_info != nullptr) {
+        int c = 0;
+        for (int t = tid; t < T; t += nt) c += smooth_info[t] != 0 ? 1 : 0;
+        if (c) atomicAdd(&nbad, c);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        *flag = viol;
+        if (row != nullptr) {
+            row[0] = descent_info[0];
+            row[1] = nbad;
+            row[2] = viol;
+            row[3] = row[4] = row[5] = 0;
+            row[6] = viol && box_unsupported ? 1 : 0;
+            row[7] = 0;
+        }
+    }
+}
+
+template <int NN>
+static int plan_check16_launch(int m, int T, size_t bytes, const double* At, const double* Bt, const double* ct,
+                               const double* K, const double* k, const double* x_new, const double* xlo,
+                               const double* xhi, const double* ulo, const double* uhi, int* flag,
+                               const int* descent_info, const int* smooth_info, int box_unsupported, int* row,
+                               hipStream_t st) {
+    static bool attr = false;
+    auto kern = plan_check16_kernel<NN>;
+    if (!attr) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) {
+            irs_set_error("plan check: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return IRS_ERR_HIP;
+        }
+        attr = true;
+    }
+    // as many 64-lane waves as there are groups of four tails, at most 16
+    const int waves = (T + 3) / 4 < 16 ? (T + 3) / 4 : 16;
+    hipLaunchKernelGGL(kern, dim3(1), dim3(64 * waves), bytes, st, m, T, At, Bt, ct, K, k, x_new, xlo, xhi, ulo, uhi, flag,
+                       descent_info, smooth_info, box_unsupported, row);
+    return IRS_OK;
+}
+
+// launches the fast kernel when the closed loops fit LDS and n, m <= 16 (else the serial one)
+static int plan_check_launch(int n, int m, int T, const double* At, const double* Bt, const double* ct, const double* K,
+                             const double* k, const double* x_new, const double* xlo, const double* xhi,
+                             const double* ulo, const double* uhi, int* flag, const int* descent_info,
+                             const int* smooth_info, int box_unsupported, int* row, hipStream_t st) {
+    const size_t bytes = (size_t)T * ((size_t)n * n + n + (size_t)n * m + m) * sizeof(double);
+    if (n >= 1 && n <= 16 && m <= 16 && bytes <= (size_t)(150 * 1024)) {
+#define PC_CASE(NN_)                                                                                                    \
+    case NN_:                                                                                                           \
+        return plan_check16_launch<NN_>(m, T, bytes, At, Bt, ct, K, k, x_new, xlo, xhi, ulo, uhi, flag, descent_info,   \
+                                        smooth_info, box_unsupported, row, st);
+        switch (n) {
+            PC_CASE(1) PC_CASE(2) PC_CASE(3) PC_CASE(4) PC_CASE(5) PC_CASE(6) PC_CASE(7) PC_CASE(8)
+            PC_CASE(9) PC_CASE(10) PC_CASE(11) PC_CASE(12) PC_CASE(13) PC_CASE(14) PC_CASE(15) PC_CASE(16)
+        }
+#undef PC_CASE
+    }
+    const int block = T < 256 ? ((T + 63) / 64 * 64) : 256;
+    hipLaunchKernelGGL(plan_check_kernel, dim3(1), dim3(block), 0, st, n, m, T, At, Bt, ct, K, k, x_new, xlo, xhi, ulo, uhi,
+                       flag, descent_info, smooth_info, box_unsupported, row);
+    return IRS_OK;
+}
+
 // row of the iteration's info history: [0] Riccati info, [1] timesteps whose smoothing solve failed, [2] box needed,
 // [3..5] the bounded descent's info (valid when [2] != 0), [6] box needed but the horizon does not fit its kernel.
 // Written by plan_check_kernel (bounds given) or by the descent's own launch (no bounds: tvlqr.hip, descent_kernel).
@@ -121,9 +287,9 @@ int irs_tvlqr_plan_within_bounds(int n, int m, int T, const double* At, const do
                                  const double* xhi, const double* ulo, const double* uhi, int* flag, void* stream) {
     IRS_CHECK_ARG(n > 0 && n <= 32 && m > 0 && m <= 16 && T > 0, "sizes out of range (n <= 32, m <= 16)");
     IRS_CHECK_ARG(At && Bt && ct && K && k && x_new && xlo && xhi && ulo && uhi && flag, "null pointer");
-    const int block = T < 256 ? ((T + 63) / 64 * 64) : 256;
-    hipLaunchKernelGGL(plan_check_kernel, dim3(1), dim3(block), 0, static_cast<hipStream_t>(stream), n, m, T, At, Bt,
-                       ct, K, k, x_new, xlo, xhi, ulo, uhi, flag, nullptr, nullptr, 0, nullptr);
+    const int rc = plan_check_launch(n, m, T, At, Bt, ct, K, k, x_new, xlo, xhi, ulo, uhi, flag, nullptr, nullptr, 0, nullptr,
+                                     static_cast<hipStream_t>(stream));
+    if (rc != IRS_OK) return rc;
     IRS_CHECK_LAUNCH();
     return IRS_OK;
 }
@@ -206,10 +372,9 @@ int irs_iterate(const irs_iterate_call* c, irs_timing* timing, void* stream) {
         if (rc != IRS_OK) return rc;
         tm.mark(2);
         if (bounded) {
-            const int block = T < 256 ? ((T + 63) / 64 * 64) : 256;
-            hipLaunchKernelGGL(plan_check_kernel, dim3(1), dim3(block), 0, st, n, m, T, At, Bt, ct, K, k, x_new, c->xlo,
-                               c->xhi, c->ulo, c->uhi, box_flag, descent_info, exact ? nullptr : smooth_info,
-                               box_fits ? 0 : 1, c->info_hist + (size_t)it * 8);
+            rc = plan_check_launch(n, m, T, At, Bt, ct, K, k, x_new, c->xlo, c->xhi, c->ulo, c->uhi, box_flag, descent_info,
+                                   exact ? nullptr : smooth_info, box_fits ? 0 : 1, c->info_hist + (size_t)it * 8, st);
+            if (rc != IRS_OK) return rc;
             if (box_fits) {
                 rc = irs_tvlqr_box_descent_if(c->model, c->params, c->n_params, T, At, Bt, ct, c->Q, c->Qd, c->R,
                                               c->alpha_R, c->xd_trj, x_nom, c->xlo, c->xhi, c->ulo, c->uhi,
