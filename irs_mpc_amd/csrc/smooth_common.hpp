@@ -2,6 +2,7 @@
 // uniform-geometry pass of the exact 8-row contact models): traits of the statistics layout, the launch
 // arguments, the per-timestep solve (finalize_timestep) and the inter-workgroup hand-off (smooth_finish).
 #pragma once
+#include <type_traits>
 #include <cstdlib>
 #include "irs_common.hpp"
 #include "philox.hpp"
@@ -54,6 +55,30 @@ constexpr size_t fnom_bytes(int T) { return (size_t)T * 32 * sizeof(double); }
 template <class Model, int MODE>
 constexpr bool nominal_in_wg0() { return !Model::HAS_JACOBIAN; }
 constexpr int kNominalCost = 3;      // the f64 nominal step costs about this many f32 sample evaluations
+
+// models with a hand-derived Jacobian in compact form (models.hpp: NJ, step_jac, expand_jac)
+template <class M, class = void>
+struct has_compact_jac : std::false_type {};
+template <class M>
+struct has_compact_jac<M, std::void_t<decltype(M::NJ)>> : std::true_type {};
+template <class M>
+constexpr int compact_jac_len() {
+    if constexpr (has_compact_jac<M>::value) return M::NJ;
+    else return 0;
+}
+
+// waves per SIMD the sample pass is compiled for (the second __launch_bounds__ argument of HIP).  A first-order pass
+// with the compact hand-derived Jacobian needs ~100 registers in its loop; what would hold the FUSED kernel at two
+// waves per SIMD is the one f64 nominal step of its solve (218 registers), run by one wave per timestep at the very
+// end -- that code is told to fit 128 registers (it spills a little, once) so that the loop runs four waves deep and
+// hides the latency of its own sample loads.
+#ifndef IRS_FO_WAVES
+#define IRS_FO_WAVES 1
+#endif
+template <class Model, int MODE>
+constexpr int smooth_min_waves() {
+    return (MODE == IRS_SMOOTH_FIRST_ORDER && has_compact_jac<Model>::value) ? IRS_FO_WAVES : 1;
+}
 
 template <class Model, int MODE>
 struct SmoothTraits {
