@@ -12,6 +12,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from oracle import irs_oracle as orc  # noqa: E402
 
 
+DEVICE_MU = os.environ.get("PDAS_DEVICE_MU", "1") == "1"
+
+
 def solve(prob, s_start, t0, lo, hi, u, act, W, valid_from, strategy, pdas_iter=10, max_iter=2000, tol=1e-10):
     """ctrlbox_solve with a choice of phase-1 strategy; returns additionally the forward steps rolled."""
     T, m = prob["B"].shape[0], prob["m"]
@@ -25,15 +28,25 @@ def solve(prob, s_start, t0, lo, hi, u, act, W, valid_from, strategy, pdas_iter=
             orc.ctrlbox_backward(prob, act, lo, hi, t_hi, t0, W)
             cnt["swept"] += t_hi - t0 + 1
 
-    def policy_rollout(us):
+    def policy_rollout(us, clipped=False):
         s[t0] = s_start
         for t in range(t0, T):
             us[t] = W["K"][t] @ s[t] + W["k"][t]
-            mu[t] = W["H"][t] @ us[t] + W["G"][t] @ s[t] + W["g"][t]
-            s[t + 1] = A[t] @ s[t] + B[t] @ us[t] + c[t]
+            uc = np.clip(us[t], lo[t], hi[t]) if clipped else us[t]
+            # (the device's multiplier rows are Y s~ = H K s + ... : the policy's own control, not the clipped one)
+            mu[t] = W["H"][t] @ (us[t] if DEVICE_MU else uc) + W["G"][t] @ s[t] + W["g"][t]
+            s[t + 1] = A[t] @ s[t] + B[t] @ uc + c[t]
         cnt["fwd"] += T - t0
 
     t_dirty = T - 1 if valid_from >= T else (valid_from - 1 if valid_from > t0 else t0 - 1)
+    # composable: "wr10_60+clip3" = the damped rule from round 11 on, the first three rounds of a tail clipped
+    clipk = 0
+    if "+" in strategy:
+        strategy, extra = strategy.split("+", 1)
+        if extra.startswith("clip"):
+            clipk = int(extra[4:])
+    elif strategy.startswith("clip"):
+        clipk = int(strategy[4:])
     n1 = pdas_iter
     if strategy.startswith("more"):
         n1 = int(strategy[4:])
@@ -46,7 +59,8 @@ def solve(prob, s_start, t0, lo, hi, u, act, W, valid_from, strategy, pdas_iter=
     while it < n1:
         it += 1
         backward(t_dirty)
-        policy_rollout(u)
+        # clipK: the first K rounds of a tail roll the policy out with the controls CLIPPED to their boxes
+        policy_rollout(u, clipped=it <= clipk)
         a, uu, mm = act[t0:], u[t0:], mu[t0:]
         new = a.copy()
         add_lo = (a == 0) & (uu < lo[t0:] - tol)
