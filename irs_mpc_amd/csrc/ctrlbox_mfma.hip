@@ -706,6 +706,7 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
         }
         const int gofs = col < L::GR ? col : 0;
         const bool out_lane = col == 0 && rg < M;
+        const int cj = rg < M ? rg : 0;
         // What a step costs is its instruction count, not the latency of its three products: a lone wave issues in
         // order, so only what stands BETWEEN two dependent matrix instructions runs in their shadow (64 cycles
         // each), and an LDS or f64-compare instruction costs ~10 cycles there (measured: the chain alone 216 cycles
@@ -713,79 +714,117 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
         // adds -- 480).  The loop therefore only loads the tile and stores the RAW output row (register RN: K~_j s~
         // of a free component, the multiplier Y_j s~ of a pinned one) into mu_; controls and multipliers are sorted
         // out afterwards, four (t, j) entries per lane at once.
-        struct Fw { double g[KA]; double ba, lo, hi, ac; };
-        const double* gp = Gt + (size_t)t0 * L::GT + (size_t)rg * L::GR + gofs;
-        // clip operands of lane (col 0, rg < M): its component's box and state; every lane: its element of B~ (A-operand)
-        const int cj = rg < M ? rg : 0;
-        int tq = t0;
-        auto fetch = [&](Fw& f) {
+        struct Fw { double g[KA]; double ti, lo, hi, ac; };
+        // steps ta .. tb-1 from state S (returned in S); `clipping`: free controls clipped as the rollout goes -- the
+        // three bound reads and the ~10 dependent f64 instructions between two steps' products make that step 520
+        // cycles instead of 320, which is why the caller below only turns it on where something does clip
+        auto roll_range = [&](int ta, int tb, v4d& S, bool clipping) {
+            const double* gp = Gt + (size_t)ta * L::GT + (size_t)rg * L::GR + gofs;
+            int tq = ta;
+            auto fetch = [&](Fw& f) {
 #pragma unroll
-            for (int s = 0; s < KA; ++s) f.g[s] = gp[4 * s * L::GR];
-            gp += L::GT;
-            if (clip) {
-                f.ba = (double)tq;              // the step's index: its element of B~ is fetched only if something clips
-                f.lo = lo_[(size_t)tq * M + cj];
-                f.hi = hi_[(size_t)tq * M + cj];
-                f.ac = act_[(size_t)tq * M + cj];
-                ++tq;
-            }
-        };
-        // every lane stores (records in LDS): lanes without an output aim at `junk`, stride 0 -- a store under an
-        // exec-mask branch would make the count of outstanding LDS operations unknown to the compiler
-        double* mo = (out_lane || !LDSREC) ? mu_ + (size_t)t0 * M + (rg < M ? rg : 0) : junk + lane;
-        const int mstride = (out_lane || !LDSREC) ? M : 0;
-        auto emit = [&](const v4d& Dp) {
-            if constexpr (LDSREC) *mo = Dp[RN];
-            else if (out_lane) *mo = Dp[RN];
-            mo += mstride;
-        };
-        auto step = [&](const Fw& f, const v4d& Sin, v4d& Sout, bool has_prev) {
-            v4d Dn = {0.0, 0.0, 0.0, 0.0};
-            Dn = __builtin_amdgcn_mfma_f64_16x16x4f64(col < L::GR ? f.g[0] : 0.0, Sin[0], Dn, 0, 0, 0);
-            if (has_prev) emit(Sin);                           // the previous step's outputs, in this product's shadow
-#pragma unroll
-            for (int s = 1; s < KA; ++s)
-                Dn = __builtin_amdgcn_mfma_f64_16x16x4f64(col < L::GR ? f.g[s] : 0.0, Sin[s], Dn, 0, 0, 0);
-            if (clip) {
-                // register RN of lane (col 0, rg) is nu_rg of this step (the multiplier for a pinned component: left
-                // alone) and, as the fourth k-group of the B operand, the place of delta_rg
-                const double raw = Dn[RN];
-                const double cl = fmin(fmax(raw, f.lo), f.hi);
-                const double dlt = (out_lane && f.ac == 0.0) ? cl - raw : 0.0;
-                // (most steps clip nothing: the product only where some lane has a delta)
-                // (B~ comes from L2, a microsecond away: prefetching it every step cost 200 cycles per step)
-                if (__ballot(dlt != 0.0) != 0ull) {
-                    const double bav = fp[4][(long)(int)f.ba * fstr[4]];
-                    Dn = __builtin_amdgcn_mfma_f64_16x16x4f64(fld[4] ? bav : fc[4], dlt, Dn, 0, 0, 0);
+                for (int s = 0; s < KA; ++s) f.g[s] = gp[4 * s * L::GR];
+                gp += L::GT;
+                if (clipping) {
+                    f.ti = (double)tq;              // the step's index: its element of B~ is fetched only if something clips
+                    f.lo = lo_[(size_t)tq * M + cj];
+                    f.hi = hi_[(size_t)tq * M + cj];
+                    f.ac = act_[(size_t)tq * M + cj];
+                    ++tq;
                 }
+            };
+            // every lane stores (records in LDS): lanes without an output aim at `junk`, stride 0 -- a store under an
+            // exec-mask branch would make the count of outstanding LDS operations unknown to the compiler
+            double* mo = (out_lane || !LDSREC) ? mu_ + (size_t)ta * M + (rg < M ? rg : 0) : junk + lane;
+            const int mstride = (out_lane || !LDSREC) ? M : 0;
+            auto emit = [&](const v4d& Dp) {
+                if constexpr (LDSREC) *mo = Dp[RN];
+                else if (out_lane) *mo = Dp[RN];
+                mo += mstride;
+            };
+            auto step = [&](const Fw& f, const v4d& Sin, v4d& Sout, bool has_prev) {
+                v4d Dn = {0.0, 0.0, 0.0, 0.0};
+                Dn = __builtin_amdgcn_mfma_f64_16x16x4f64(col < L::GR ? f.g[0] : 0.0, Sin[0], Dn, 0, 0, 0);
+                if (has_prev) emit(Sin);                           // the previous step's outputs, in this product's shadow
+#pragma unroll
+                for (int s = 1; s < KA; ++s)
+                    Dn = __builtin_amdgcn_mfma_f64_16x16x4f64(col < L::GR ? f.g[s] : 0.0, Sin[s], Dn, 0, 0, 0);
+                if (clipping) {
+                    // register RN of lane (col 0, rg) is nu_rg of this step (the multiplier for a pinned component: left
+                    // alone) and, as the fourth k-group of the B operand, the place of delta_rg
+                    const double raw = Dn[RN];
+                    const double cl = fmin(fmax(raw, f.lo), f.hi);
+                    const double dlt = (out_lane && f.ac == 0.0) ? cl - raw : 0.0;
+                    // (the product only where some lane has a delta; B~ comes from L2, a microsecond away: prefetching
+                    // it every step cost 200 cycles per step)
+                    if (__ballot(dlt != 0.0) != 0ull) {
+                        const double bav = fp[4][(long)(int)f.ti * fstr[4]];
+                        Dn = __builtin_amdgcn_mfma_f64_16x16x4f64(fld[4] ? bav : fc[4], dlt, Dn, 0, 0, 0);
+                    }
+                }
+                Sout = Dn;
+            };
+            // two steps per trip: the prefetched operands and the state tile alternate between two register sets,
+            // so nothing is copied at the back edge (a lone wave pays ~5 cycles for every v_mov)
+            Fw fa, fb;
+            v4d S1;
+            fetch(fa);
+            int t = ta;
+            bool hp = false;
+            for (; t + 1 < tb; t += 2) {
+                fetch(fb);
+                step(fa, S, S1, hp);
+                if (t + 2 < tb) fetch(fa);
+                step(fb, S1, S, true);
+                hp = true;
             }
-            Sout = Dn;
+            if (t < tb) {
+                step(fa, S, S1, hp);
+                emit(S1);
+                S = S1;
+            } else if (hp) {
+                emit(S);
+            }
         };
-        // two steps per trip: the prefetched operands and the state tile alternate between two register sets,
-        // so nothing is copied at the back edge (a lone wave pays ~5 cycles for every v_mov)
-        Fw fa, fb;
-        v4d S1;
-        fetch(fa);
-        int t = t0;
-        bool hp = false;
 #ifdef IRS_CBM_STAMPS
         const long long st_fl0 = __builtin_amdgcn_s_memtime();
 #endif
-        for (; t + 1 < te; t += 2) {
-            fetch(fb);
-            step(fa, S, S1, hp);
-            if (t + 2 < te) fetch(fa);
-            step(fb, S1, S, true);
-            hp = true;
-        }
-        if (t < te) {
-            step(fa, S, S1, hp);
-            emit(S1);
-        } else if (hp) {
-            emit(S);
+        if (!clip) {
+            roll_range(t0, te, S, false);
+        } else {
+            // plain steps, kCheck at a time, until a free control leaves its box inside a chunk: that chunk is redone, and
+            // the rest done, with clipping.  (The accepted round of every tail, and the head of most others, clips nothing.)
+            constexpr int kCheck = 16;
+            int t = t0;
+            bool found = false;
+            while (t < te && !found) {
+                const int tc = min(t + kCheck, te);
+                const v4d Ssave = S;
+                roll_range(t, tc, S, false);
+#ifdef IRS_CBM_STAMPS
+                st_acc[20] += tc - t;
+                st_acc[21] += 1;
+#endif
+                rsync();
+                bool v = false;
+                for (int q = t * M + lane; q < tc * M; q += 64) {
+                    const double raw = mu_[q];
+                    v = v || (act_[q] == 0.0 && (raw < lo_[q] || raw > hi_[q]));
+                }
+                if (__any(v)) {
+                    S = Ssave;
+                    found = true;
+                } else {
+                    t = tc;
+                }
+            }
+#ifdef IRS_CBM_STAMPS
+            st_acc[19] += te - t;
+#endif
+            if (t < te) roll_range(t, te, S, true);
         }
 #ifdef IRS_CBM_STAMPS
-        asm volatile("" :: "v"(S[0]), "v"(S1[0]));
+        asm volatile("" :: "v"(S[0]));
         st_acc[13] += __builtin_amdgcn_s_memtime() - st_fl0;
         st_acc[12] += 1;
 #endif
@@ -1189,5 +1228,6 @@ extern "C" void irs_cbm_print_stamps(void) {
                     "pinned head: %lld (%lld of those sweeps released a component)\n", h[12], h[13], h[14], h[15]);
     fprintf(stderr, "[cbm stamps] active-set iterations over all tails: %lld; tails that left the primal-dual phase unconverged: %lld "
                     "(after %lld iterations)\n", h[17], h[16], h[18]);
+    fprintf(stderr, "[cbm stamps] clipped rollouts: %lld plain steps in %lld chunks, %lld clipping steps\n", h[20], h[21], h[19]);
 }
 #endif
