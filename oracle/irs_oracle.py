@@ -1564,18 +1564,21 @@ def ctrlbox_solve(prob, s_start, t0, lo, hi, u, act, W, valid_from, pdas_iter=10
             ctrlbox_backward(prob, act, lo, hi, t_hi, t0, W)
             swept += t_hi - t0 + 1
 
-    def policy_rollout(us):
+    def policy_rollout(us, clip=False):
+        # clip (csrc/ctrlbox_mfma.hip, round 3; trust-region problems, phase 1): the rollout applies the controls
+        # CLIPPED to their boxes, so that the violations a round reports are those of a trajectory that stays in the
+        # box upstream.  Only an update rule: the accepted round clips nothing.
         s[t0] = s_start
         for t in range(t0, T):
             us[t] = W["K"][t] @ s[t] + W["k"][t]
             mu[t] = W["H"][t] @ us[t] + W["G"][t] @ s[t] + W["g"][t]
-            s[t + 1] = A[t] @ s[t] + B[t] @ us[t] + c[t]
+            s[t + 1] = A[t] @ s[t] + B[t] @ (np.clip(us[t], lo[t], hi[t]) if clip else us[t]) + c[t]
 
     t_dirty = T - 1 if valid_from >= T else (valid_from - 1 if valid_from > t0 else t0 - 1)
     # ---- phase 1: primal-dual active set
     for it in range(1, pdas_iter + single_iter + 1):
         backward(t_dirty)
-        policy_rollout(u)
+        policy_rollout(u, clip=prob.get("kind") == "abs")
         a, uu, mm = act[t0:], u[t0:], mu[t0:]
         new = a.copy()
         new[(a == 0) & (uu < lo[t0:] - tol)] = -1
