@@ -735,8 +735,8 @@ def test_box_pushing_input_jacobian_matches_simulator(golden_dir):
 
 def test_saturated_start_same_solution_fewer_sweeps():
     """The cold start of the matrix-core descent kernel (saturated unconstrained policy) restated: the T
-    re-solved tail QPs have the same solutions from either starting set, and the benchmark-like problem
-    (planar hand, trust region binding on about half the components) needs fewer backward time steps."""
+    re-solved tail QPs have the same solutions from either starting set, and on the benchmark-like problem
+    (planar hand, trust region binding on about half the components) it costs no more backward time steps."""
     T = 30
     o = orc.PlanarHandOracle(0.1)
     idx = o.indices_u_into_x
@@ -755,7 +755,10 @@ def test_saturated_start_same_solution_fewer_sweeps():
         np.testing.assert_allclose(ub, ua, rtol=0, atol=1e-9)
         np.testing.assert_allclose(xb, xa, rtol=0, atol=1e-9)
         if kind == "abs":
-            assert sum(s[2] for s in st_b) < 0.8 * sum(s[2] for s in st_a)
+            # (until the primal-dual rounds themselves rolled out CLIPPED controls -- round 3 -- the saturated start
+            # needed a third of the backward steps of the cold one here; now every round is such a rollout and the
+            # two starts cost the same)
+            assert sum(s[2] for s in st_b) < 1.1 * sum(s[2] for s in st_a)
 
 
 # ---- the metric's own contact model, pinned by the reference's result files ---------------------------------
