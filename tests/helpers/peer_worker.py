@@ -42,6 +42,19 @@ def main():
     parts = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(parts, mine)
     assert all(torch.equal(parts[0], p) for p in parts)
+    # a peer that does not arrive: rank 0 issues one exchange more than the others.  Its wait must END (bounded by
+    # IRS_PEER_TIMEOUT_MS), poison the statistics and count a timeout -- not hang the GPU
+    dist.barrier()
+    if "--missing-peer" in sys.argv and world > 1:
+        if rank == 0:
+            extra = torch.ones(count, dtype=torch.float64, device="cuda")
+            px.all_reduce_sums(extra)
+            torch.cuda.synchronize()
+            launches, timeouts = px.status()
+            assert timeouts == 1 and launches == steps + 1, (launches, timeouts)
+            assert bool(torch.isnan(extra).all()), "a timed-out exchange must poison the statistics"
+            print("PEER_TIMEOUT_OK", flush=True)
+        dist.barrier()
     px.destroy()
     dist.barrier()
     if rank == 0:

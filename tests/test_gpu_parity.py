@@ -1215,12 +1215,15 @@ def test_peer_exchange_two_ranks_on_one_gpu():
     memory model across two L2s: that needs a multi-GPU node; include/irs_hip.h says so.)"""
     import subprocess
     import sys
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", IRS_PEER_TIMEOUT_MS="5000")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", IRS_PEER_TIMEOUT_MS="1500")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "tests", "helpers", "peer_worker.py")]
+           "--master-addr", "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "tests", "helpers", "peer_worker.py"),
+           "--missing-peer"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
     assert "PEER_EXCHANGE_OK world=2" in r.stdout
+    # ... and a peer that never arrives ends the wait after IRS_PEER_TIMEOUT_MS with poisoned statistics (no hang)
+    assert "PEER_TIMEOUT_OK" in r.stdout
 
 
 def test_bench_two_ranks_peer_exchange_on_one_gpu():
