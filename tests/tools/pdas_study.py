@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from oracle import irs_oracle as orc  # noqa: E402
 
 
+FROZEN_TOTAL = []
 DEVICE_MU = os.environ.get("PDAS_DEVICE_MU", "1") == "1"
 
 
@@ -22,6 +23,7 @@ def solve(prob, s_start, t0, lo, hi, u, act, W, valid_from, strategy, pdas_iter=
     s = np.zeros((T + 1, A.shape[1]))
     mu = np.zeros((T, m))
     cnt = dict(swept=0, fwd=0)
+    FROZEN_TOTAL.append(cnt)
 
     def backward(t_hi):
         if t_hi >= t0:
@@ -53,6 +55,9 @@ def solve(prob, s_start, t0, lo, hi, u, act, W, valid_from, strategy, pdas_iter=
     wr_after = None
     if strategy.startswith("wr"):           # wrK_N: all adds + only the worst release from iteration K+1 on, N iterations
         wr_after, n1 = (int(v) for v in strategy[2:].split("_"))
+    if strategy == "frozen":
+        return solve_frozen(prob, s_start, t0, lo, hi, u, act, W, valid_from, clipk > 0, backward, policy_rollout, cnt, s, mu,
+                            tol)
     seen = {}
     it = 0
     mode_add_only = False
@@ -165,6 +170,49 @@ def solve(prob, s_start, t0, lo, hi, u, act, W, valid_from, strategy, pdas_iter=
     return s, u, mu, (it, -max_iter, cnt["swept"], cnt["fwd"]), t0
 
 
+def solve_frozen(prob, s_start, t0, lo, hi, u, act, W, valid_from, clip, backward, policy_rollout, cnt, s, mu, tol):
+    """Outer rounds = exact sweeps; inner rounds keep the cost-to-go FROZEN and recompute the gains of the changed steps
+    only (each from its stored P_{t+1}), then roll out again.  cnt["frozen"] counts the single-step updates."""
+    T = prob["B"].shape[0]
+    cnt["frozen"] = 0
+    t_dirty = T - 1 if valid_from >= T else (valid_from - 1 if valid_from > t0 else t0 - 1)
+
+    def update():
+        a, uu, mm = act[t0:], u[t0:], mu[t0:]
+        new = a.copy()
+        new[(a == 0) & (uu < lo[t0:] - tol)] = -1
+        new[(a == 0) & (uu > hi[t0:] + tol)] = 1
+        new[((a < 0) & (mm < -tol)) | ((a > 0) & (mm > tol))] = 0
+        changed = np.nonzero((new != a).any(axis=1))[0]
+        act[t0:] = new
+        return changed
+
+    outer = 0
+    while outer < 60:
+        outer += 1
+        backward(t_dirty)                     # exact
+        policy_rollout(u, clipped=clip)
+        changed = update()
+        if changed.size == 0:
+            return s, u, mu, (outer, 0, cnt["swept"], cnt["fwd"]), t0
+        hi_changed = int(changed.max())
+        # inner rounds with frozen P
+        for inner in range(20):
+            for r in changed[::-1]:
+                t = t0 + int(r)
+                Psave, psave = W["P"][t].copy(), W["p"][t].copy()
+                orc.ctrlbox_backward(prob, act, lo, hi, t, t, W)
+                W["P"][t], W["p"][t] = Psave, psave
+                cnt["frozen"] += 1
+            policy_rollout(u, clipped=clip)
+            changed = update()
+            if changed.size == 0:
+                break
+            hi_changed = max(hi_changed, int(changed.max()))
+        t_dirty = t0 + hi_changed
+    return s, u, mu, (outer, -1, cnt["swept"], cnt["fwd"]), t0
+
+
 def descent(system, d, strategy, kind):
     At, Bt, ct = d["At"], d["Bt"], d["ct"]
     T, n, m = Bt.shape
@@ -204,6 +252,10 @@ def main():
         print("%-10s iterations %4d (primal-dual %d + primal %d)  backward steps %6d  forward steps %6d  tails into phase 2: %s" % (
             sname, int(st[:, 0].sum() + np.abs(st[:, 1]).sum()), int(st[:, 0].sum()), int(np.abs(st[:, 1]).sum()),
             int(st[:, 2].sum()), int(st[:, 3].sum()), failed), flush=True)
+        fz = sum(c.get("frozen", 0) for c in FROZEN_TOTAL)
+        if fz:
+            print("           single-step updates with the cost-to-go frozen: %d" % fz)
+        del FROZEN_TOTAL[:]
         if ref is None:
             ref = u_new
         else:
