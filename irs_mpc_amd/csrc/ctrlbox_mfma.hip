@@ -199,7 +199,8 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
     // barriers: S0 (the solver's tables are up), then per tail A (start state ready) and B (control ready)
     if (wave == 1) {
         double xr[NR], ur[M], xn[NR], up[M], ub[M];
-        if (lane == 0 && a.cost) a.cost[0] = __builtin_nan("");      // sentinel, like info (ctrlbox.hip)
+        // sentinel, like info (ctrlbox.hip); stored as a bit pattern: this file is compiled with -fno-honor-nans
+        if (lane == 0 && a.cost) *reinterpret_cast<unsigned long long*>(a.cost) = 0x7ff8000000000000ull;
 #pragma unroll
         for (int i = 0; i < NR; ++i) xr[i] = a.x0[i];
 #pragma unroll

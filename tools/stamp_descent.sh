@@ -6,7 +6,7 @@
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd $R/irs_mpc_amd/csrc
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -mllvm -amdgpu-mfma-vgpr-form=1 \
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -mllvm -amdgpu-mfma-vgpr-form=1 -fno-honor-nans -fno-signed-zeros \
     -DIRS_CBM_STAMPS -c ctrlbox_mfma.hip -o /tmp/ctrlbox_mfma_stamps.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/gpurun_out/libirs_hip_stamps.so plugin.o smooth.o smooth_ug.o tvlqr.o cem.o boxqp.o ctrlbox.o collective.o iterate.o /tmp/ctrlbox_mfma_stamps.o -ldl
 cd $R
