@@ -76,8 +76,10 @@ __device__ __forceinline__ double readlane_d(double v, int src) {
 template <int N>
 __device__ __forceinline__ double row_newbcast_d(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + N, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + N, 0xf, 0xf, false);
+    // (bound_ctrl set: every lane has a valid source, and with it the compiler need not initialise the destination --
+    // it emitted a v_mov of zero per word and broadcast otherwise, 22 per backward step)
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + N, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + N, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wmax_d(double v) {
