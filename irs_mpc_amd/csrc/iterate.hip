@@ -84,8 +84,8 @@ __global__ void plan_check_kernel(int n, int m, int T, const double* __restrict_
 template <int N>
 __device__ __forceinline__ double pc_row_bcast(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + N, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + N, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + N, 0xf, 0xf, true);     // bound_ctrl: no destination initialisation
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + N, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
