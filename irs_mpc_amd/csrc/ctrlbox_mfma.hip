@@ -797,7 +797,10 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
         } else {
             // plain steps, kCheck at a time, until a free control leaves its box inside a chunk: that chunk is redone, and
             // the rest done, with clipping.  (The accepted round of every tail, and the head of most others, clips nothing.)
-            constexpr int kCheck = 16;
+            #ifndef IRS_KCHECK
+#define IRS_KCHECK 16
+#endif
+            constexpr int kCheck = IRS_KCHECK;
             int t = t0;
             bool found = false;
             while (t < te && !found) {
