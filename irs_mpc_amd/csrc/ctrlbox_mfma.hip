@@ -438,6 +438,29 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
 #pragma unroll
             for (int r = 0; r < KA; ++r) p.q[r] = qsd[(size_t)t * NR + qidx[r]];
         };
+        // Records in LDS: the stores of step t (P~_t, the forward tile G_t) are not issued at the end of step t, where
+        // they stand between its last product and the next step's first one -- a lone wave issues in order: ~20
+        // instructions, ~250 cycles on the chain for nothing -- but in the shadow of the next step's first three
+        // products (P~_t IS that step's operand and stays in its registers; the tile's rows wait in `pendAcl`).
+        bool pend = false;
+        int pend_t = 0;
+        v4d pendAcl = {0.0, 0.0, 0.0, 0.0};
+        double pendGk = 0.0;
+        auto flush_P = [&]() {
+            double* pp = col < NHP ? Pt + (size_t)pend_t * L::PT + (size_t)rg * NHP + col : junk + lane;
+            const int ps = col < NHP ? 4 * NHP : 0;
+#pragma unroll
+            for (int r = 0; r < KA; ++r) pp[r * ps] = P[r];
+        };
+        auto flush_G = [&]() {
+            double* G = Gt + (size_t)pend_t * L::GT;
+            double* gq = col < NH ? G + (size_t)col * L::GR + rg : junk + 64 + lane;
+            const int gs = col < NH ? 4 : 0;
+#pragma unroll
+            for (int r = 0; r < KA; ++r) gq[r * gs] = pendAcl[r];
+            double* gk = (col < NH && rg < M) ? G + (size_t)col * L::GR + NHP + rg : junk + 64 + lane;
+            *gk = pendGk;
+        };
         auto bw_step = [&](int t, const Pre& cur, Pre& nxt, bool prefetch) {
 #ifdef IRS_CBM_STAMPS
             {   // how long the step waits for its prefetched (A, B, c)
@@ -465,8 +488,19 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
             if (prefetch) load_step(t - 1, nxt);               // prefetch
             // D1 = P~ F ;  Theta = L_t + F' D1
             v4d D1 = {0.0, 0.0, 0.0, 0.0};
+            if constexpr (LDSREC) {
+                D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[0], F[0], D1, 0, 0, 0);
+                if (pend) flush_P();
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (KA >= 2) D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[1], F[1], D1, 0, 0, 0);
+                if (pend) flush_G();
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < KA; ++s) D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[s], F[s], D1, 0, 0, 0);
+                for (int s = 2; s < KA; ++s) D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[s], F[s], D1, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int s = 0; s < KA; ++s) D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[s], F[s], D1, 0, 0, 0);
+            }
             v4d Th = Lt;
 #pragma unroll
             for (int s = 0; s < KA; ++s) Th = __builtin_amdgcn_mfma_f64_16x16x4f64(F[s], D1[s], Th, 0, 0, 0);
@@ -652,16 +686,10 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
             // lanes outside the tile into `junk` (no exec-mask branches: see the forward sweep)
             double* G = Gt + (size_t)t * L::GT;
             if constexpr (LDSREC) {
-                double* pp = col < NHP ? Pt + (size_t)t * L::PT + (size_t)rg * NHP + col : junk + lane;
-                const int ps = col < NHP ? 4 * NHP : 0;
-#pragma unroll
-                for (int r = 0; r < KA; ++r) pp[r * ps] = P[r];
-                double* gq = col < NH ? G + (size_t)col * L::GR + rg : junk + 64 + lane;
-                const int gs = col < NH ? 4 : 0;
-#pragma unroll
-                for (int r = 0; r < KA; ++r) gq[r * gs] = Acl[r];
-                double* gk = (col < NH && rg < M) ? G + (size_t)col * L::GR + NHP + rg : junk + 64 + lane;
-                *gk = my_free ? Kb : D[RN];
+                pend = true;
+                pend_t = t;
+                pendAcl = Acl;
+                pendGk = my_free ? Kb : D[RN];
             } else {
                 if (col < NHP) {
 #pragma unroll
@@ -685,6 +713,12 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
             bw_step(t - 1, pb, pa, t - 2 >= t_lo);
         }
         if (t >= t_lo) bw_step(t, pa, pb, false);
+        if constexpr (LDSREC) {
+            if (pend) {
+                flush_P();
+                flush_G();
+            }
+        }
         rsync();
         CBM_ADD(0, t_hi - t_lo + 1);
     };
