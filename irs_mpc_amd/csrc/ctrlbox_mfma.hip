@@ -483,27 +483,60 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
                 bb[j] = cur.bd[j];
             }
             v4d Lt = Lc;
-#pragma unroll
-            for (int r = 0; r < KA; ++r) Lt[r] = qhas[r] ? cur.q[r] : Lc[r];
-            if (prefetch) load_step(t - 1, nxt);               // prefetch
-            // D1 = P~ F ;  Theta = L_t + F' D1
+            // D1 = P~ F ;  Theta = L_t + F' D1.  What is not on the chain is DEALT OUT over the gaps between the six
+            // products by hand, one scheduling barrier per gap (left to itself the compiler issues all of it in one gap:
+            // ~40 instructions behind a 64-cycle product stall the chain ~190 cycles per step)
             v4d D1 = {0.0, 0.0, 0.0, 0.0};
-            if constexpr (LDSREC) {
+            v4d Th;
+            if constexpr (LDSREC && KA == 3) {
                 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[0], F[0], D1, 0, 0, 0);
-                if (pend) flush_P();
+                if (pend) flush_P();                                             // gap 1: last step's P~ record
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (KA >= 2) D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[1], F[1], D1, 0, 0, 0);
-                if (pend) flush_G();
+                D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[1], F[1], D1, 0, 0, 0);
+                if (pend) flush_G();                                             // gap 2: last step's forward tile
                 __builtin_amdgcn_sched_barrier(0);
+                D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[2], F[2], D1, 0, 0, 0);
+                if (prefetch) load_F(t - 1, nxt.Fraw);                           // gap 3: next step's (A, B, c) from L2
 #pragma unroll
-                for (int s = 2; s < KA; ++s) D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[s], F[s], D1, 0, 0, 0);
+                for (int r = 0; r < KA; ++r) Lt[r] = qhas[r] ? cur.q[r] : Lc[r];
+                __builtin_amdgcn_sched_barrier(0);
+                Th = __builtin_amdgcn_mfma_f64_16x16x4f64(F[0], D1[0], Lt, 0, 0, 0);
+                if (prefetch) {                                                  // gap 4: next step's set and bounds
+#pragma unroll
+                    for (int j = 0; j < M; ++j) {
+                        nxt.ac[j] = act_[(size_t)(t - 1) * M + j];
+                        nxt.bd[j] = bnd_[(size_t)(t - 1) * M + j];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                Th = __builtin_amdgcn_mfma_f64_16x16x4f64(F[1], D1[1], Th, 0, 0, 0);
+                if (prefetch) {                                                  // gap 5: next step's -Qs sd entries
+#pragma unroll
+                    for (int r = 0; r < KA; ++r) nxt.q[r] = qsd[(size_t)(t - 1) * NR + qidx[r]];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                Th = __builtin_amdgcn_mfma_f64_16x16x4f64(F[2], D1[2], Th, 0, 0, 0);
             } else {
 #pragma unroll
-                for (int s = 0; s < KA; ++s) D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[s], F[s], D1, 0, 0, 0);
-            }
-            v4d Th = Lt;
+                for (int r = 0; r < KA; ++r) Lt[r] = qhas[r] ? cur.q[r] : Lc[r];
+                if (prefetch) load_step(t - 1, nxt);               // prefetch
+                if constexpr (LDSREC) {
+                    D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[0], F[0], D1, 0, 0, 0);
+                    if (pend) flush_P();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (KA >= 2) D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[1], F[1], D1, 0, 0, 0);
+                    if (pend) flush_G();
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < KA; ++s) Th = __builtin_amdgcn_mfma_f64_16x16x4f64(F[s], D1[s], Th, 0, 0, 0);
+                    for (int s = 2; s < KA; ++s) D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[s], F[s], D1, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < KA; ++s) D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[s], F[s], D1, 0, 0, 0);
+                }
+                Th = Lt;
+#pragma unroll
+                for (int s = 0; s < KA; ++s) Th = __builtin_amdgcn_mfma_f64_16x16x4f64(F[s], D1[s], Th, 0, 0, 0);
+            }
             // H = Theta_nu,nu to every lane (symmetric: 10 of 16 by readlane); this lane's column of
             // Theta_nu,: (rows NHP + i sit in register RN of lanes 16 i + col).
             // The active set enters as 0/1 factors mf_i (free) -- products instead of per-element selects: a
