@@ -516,6 +516,29 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 Th = __builtin_amdgcn_mfma_f64_16x16x4f64(F[2], D1[2], Th, 0, 0, 0);
+            } else if constexpr (LDSREC && KA == 2) {
+                // (the 8-row tiles: four products, three gaps)
+                D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[0], F[0], D1, 0, 0, 0);
+                if (pend) flush_P();
+                __builtin_amdgcn_sched_barrier(0);
+                D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[1], F[1], D1, 0, 0, 0);
+                if (pend) flush_G();
+                if (prefetch) load_F(t - 1, nxt.Fraw);
+#pragma unroll
+                for (int r = 0; r < KA; ++r) Lt[r] = qhas[r] ? cur.q[r] : Lc[r];
+                __builtin_amdgcn_sched_barrier(0);
+                Th = __builtin_amdgcn_mfma_f64_16x16x4f64(F[0], D1[0], Lt, 0, 0, 0);
+                if (prefetch) {
+#pragma unroll
+                    for (int j = 0; j < M; ++j) {
+                        nxt.ac[j] = act_[(size_t)(t - 1) * M + j];
+                        nxt.bd[j] = bnd_[(size_t)(t - 1) * M + j];
+                    }
+#pragma unroll
+                    for (int r = 0; r < KA; ++r) nxt.q[r] = qsd[(size_t)(t - 1) * NR + qidx[r]];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                Th = __builtin_amdgcn_mfma_f64_16x16x4f64(F[1], D1[1], Th, 0, 0, 0);
             } else {
 #pragma unroll
                 for (int r = 0; r < KA; ++r) Lt[r] = qhas[r] ? cur.q[r] : Lc[r];
