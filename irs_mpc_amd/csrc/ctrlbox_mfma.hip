@@ -1072,24 +1072,34 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
             int chg = -1;
             double rworst = 0.0;
             int rq = 0x7fffffff;
-            for (int q = t0 * M + lane; q < T * M; q += 64) {
-                const double ac = act_[q], u = uu_[q], mu = mu_[q];
-                const bool fresh = q / M > stale_hi;   // multipliers of the skipped prefix are not current
-                double nw = ac;
-                if (ac == 0.0) {
-                    if (u < lo_[q] - tol) nw = -1.0;
-                    else if (u > hi_[q] + tol) nw = 1.0;
-                } else if (ac < 0.0) {
-                    if (fresh && mu < -tol) nw = 0.0;
-                } else {
-                    if (fresh && mu > tol) nw = 0.0;
+            // (every lane runs every trip -- `chg` comes out of a ballot and must be the same in all of them)
+            for (int qb = t0 * M; qb < T * M; qb += 64) {
+                const int q = qb + lane;
+                bool changed = false;
+                if (q < T * M) {
+                    const double ac = act_[q], u = uu_[q], mu = mu_[q];
+                    const bool fresh = q / M > stale_hi;   // multipliers of the skipped prefix are not current
+                    double nw = ac;
+                    if (ac == 0.0) {
+                        if (u < lo_[q] - tol) nw = -1.0;
+                        else if (u > hi_[q] + tol) nw = 1.0;
+                    } else if (ac < 0.0) {
+                        if (fresh && mu < -tol) nw = 0.0;
+                    } else {
+                        if (fresh && mu > tol) nw = 0.0;
+                    }
+                    if (single && nw == 0.0 && ac != 0.0) {     // a release: remembered, not applied
+                        const double v = fabs(mu);
+                        if (v > rworst) { rworst = v; rq = q; }
+                        nw = ac;
+                    }
+                    changed = nw != ac;
+                    if (changed) { act_[q] = nw; bnd_[q] = nw < 0.0 ? lo_[q] : hi_[q]; sig_[q / M] = -1.0; }
                 }
-                if (single && nw == 0.0 && ac != 0.0) {     // a release: remembered, not applied
-                    const double v = fabs(mu);
-                    if (v > rworst) { rworst = v; rq = q; }
-                    nw = ac;
-                }
-                if (nw != ac) { act_[q] = nw; bnd_[q] = nw < 0.0 ? lo_[q] : hi_[q]; sig_[q / M] = -1.0; chg = max(chg, q / M); }
+                // the latest changed step, without a cross-lane reduction (a wave maximum is six LDS-crossbar
+                // shuffles, ~500 cycles per round): q grows with the lane, so it is the ballot's highest bit
+                const unsigned long long cb = __ballot(changed);
+                if (cb != 0ull) chg = max(chg, (qb + 63 - __builtin_clzll(cb)) / M);
             }
             if (single) {
                 const double wm = wmax_d(rworst);
@@ -1099,7 +1109,6 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
                     chg = max(chg, qw / M);
                 }
             }
-            chg = wmax_i(chg);
             rsync();
             if (chg < 0 && stale_hi >= t0) {
                 // the rest has settled: sweep the skipped prefix once and test ITS multipliers
@@ -1110,11 +1119,17 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
                 backward_sweep(ph, t0);
                 stale_hi = t0 - 1;
                 policy_rollout(t0, uu_, ph + 1);
-                for (int q = t0 * M + lane; q < (ph + 1) * M; q += 64) {
-                    const double ac = act_[q], mu = mu_[q];
-                    if ((ac < 0.0 && mu < -tol) || (ac > 0.0 && mu > tol)) { act_[q] = 0.0; sig_[q / M] = -1.0; chg = max(chg, q / M); }
+                for (int qb = t0 * M; qb < (ph + 1) * M; qb += 64) {
+                    const int q = qb + lane;
+                    bool rel = false;
+                    if (q < (ph + 1) * M) {
+                        const double ac = act_[q], mu = mu_[q];
+                        rel = (ac < 0.0 && mu < -tol) || (ac > 0.0 && mu > tol);
+                        if (rel) { act_[q] = 0.0; sig_[q / M] = -1.0; }
+                    }
+                    const unsigned long long cb = __ballot(rel);
+                    if (cb != 0ull) chg = max(chg, (qb + 63 - __builtin_clzll(cb)) / M);
                 }
-                chg = wmax_i(chg);
                 rsync();
 #ifdef IRS_CBM_STAMPS
                 st_acc[15] += chg >= 0 ? 1 : 0;
