@@ -2514,6 +2514,28 @@ def test_plan_within_bounds_kernel_vs_host_statement(amd):
         assert int(flag.item()) == (0 if want else 1), steer
         seen.add(bool(want))
     assert seen == {True, False}
+    # T = 200 (more tails than one pass of the workgroup holds: 64 in flight), n = 2: the pendulum's horizon in the script
+    from examples.problems import pendulum
+    T = 200
+    sysd, params, _, _, _ = pendulum(T)
+    seen = set()
+    for speed in (0.5, 3.0, 1e4):
+        params.xbound = [-np.array([1e4, speed]), np.array([1e4, speed])]
+        sol = amd.IrsLqrExact(sysd, params)
+        sol.verbose = False
+        x, u = dev.to_dev(sol.x_trj), dev.to_dev(sol.u_trj)
+        At, Bt, ct = sol._get_TV_matrices_dev(x, u)
+        o = sol._dm.tvlqr_descent(At, Bt, ct, sol._Q, sol._Qd, sol._R, sol._xd, x[0].contiguous(), alpha_R=0.5)
+        box = sol._box_bounds()
+        want = sol._tail_plans_within_bounds(At, Bt, ct, o["K"], o["k"], o["x_new"])
+        flag = torch.full((1,), -7, dtype=torch.int32, device=x.device)
+        _lib.check(_lib.load().irs_tvlqr_plan_within_bounds(2, 1, T, At.data_ptr(), Bt.data_ptr(), ct.data_ptr(),
+                                                           o["K"].data_ptr(), o["k"].data_ptr(), o["x_new"].data_ptr(),
+                                                           *(b.data_ptr() for b in box), flag.data_ptr(), dev._stream()),
+                   "irs_tvlqr_plan_within_bounds")
+        assert int(flag.item()) == (0 if want else 1), speed
+        seen.add(bool(want))
+    assert seen == {True, False}
     # n = 12 (16 lanes per tail, several tails per wave, T not a multiple of the tails in flight): the quadrotor with its
     # script's bounds and the pitch limit varied
     from examples.problems import quadrotor
