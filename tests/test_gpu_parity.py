@@ -1208,6 +1208,31 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert "all-reduce" in out["config"]["step"]
 
 
+def test_quasistatic_active_set_descent_reports_a_bad_hessian(amd):
+    """The matrix-core active-set kernel (compiled with -fno-honor-nans) still reports, through info[0], a control
+    Hessian that is not positive definite -- an indefinite cost -- and a non-finite linearisation."""
+    from irs_mpc_amd import device as dev
+    T = 8
+    sys_d, sys_o, x0, u_trj, x_trj, _, (At, Bt, ct), (Q, Qd, R, xd) = _hand_problem(amd, T, 400, 21)
+    idx = sys_o.indices_u_into_x
+    ub = np.array([-np.ones(4) * 0.05, np.ones(4) * 0.05])
+    rows = orc.quasistatic_bounds(x_trj, idx, None, ub, None)
+    rows_d = [dev.to_dev(r) if np.isfinite(r).any() else None for r in rows]
+    dm = sys_d.dm()
+    good = dm.quasistatic_box_descent(*[dev.to_dev(a) for a in (At, Bt, ct, Q, Qd, R, xd, x0)], *rows_d, solver=0,
+                                      max_iter=2000, eps=1e-10)
+    assert good["info"].cpu().numpy()[0] == 0
+    bad = dm.quasistatic_box_descent(*[dev.to_dev(a) for a in (At, Bt, ct, -50.0 * Q, -50.0 * Qd, 1e-6 * R, xd, x0)],
+                                     *rows_d, solver=0, max_iter=50, eps=1e-10)
+    assert bad["info"].cpu().numpy()[0] != 0
+    Bn = Bt.copy()
+    Bn[T // 2, 0, 0] = np.nan
+    nan = dm.quasistatic_box_descent(*[dev.to_dev(a) for a in (At, Bn, ct, Q, Qd, R, xd, x0)], *rows_d, solver=0,
+                                     max_iter=50, eps=1e-10)
+    i3 = nan["info"].cpu().numpy()
+    assert i3[0] != 0 or i3[2] != 0 or not np.isfinite(float(nan["cost"].item())), i3
+
+
 def test_peer_exchange_two_ranks_on_one_gpu():
     """The all-reduce WITHOUT a collective library (csrc/collective.hip, irs_peer_*): two processes on this one GPU map
     each other's exchange regions by IPC handle and run 300 exchange launches back to back (slot reuse) -- every rank
