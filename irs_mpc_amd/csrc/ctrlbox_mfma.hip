@@ -643,6 +643,25 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
     #pragma unroll
                         for (int j = 0; j < M; ++j) Hm[i][j] = i == j ? (ac[i] == 0.0 ? H[i][i] : 1.0) : H[i][j] * (mf[i] * mf[j]);
                 }
+                const double hsel = col == NS ? 1.0 : 0.0;
+                double rhs[M];
+    #pragma unroll
+                for (int i = 0; i < M; ++i) {
+                    // right-hand side of the free rows: Theta_f,col + (homogeneous column) sum_p H_fp b_p
+                    rhs[i] = gc[i];
+                }
+                if (pins) {
+    #pragma unroll
+                    for (int i = 0; i < M; ++i) {
+                        double hb0 = 0.0, hb1 = 0.0;
+    #pragma unroll
+                        for (int l = 0; l < M; ++l) {
+                            if (l & 1) hb1 = fma(H[i][l], bz[l], hb1);
+                            else hb0 = fma(H[i][l], bz[l], hb0);
+                        }
+                        rhs[i] = fma(hsel, hb0 + hb1, gc[i]) * mf[i];
+                    }
+                }
                 bool spd = true;
                 auto inv2 = [&](double p, double q, double r, double& ip, double& iq, double& ir) {
                     // [p q; q r]^-1 = [r -q; -q p] / (p r - q^2)
@@ -669,46 +688,29 @@ __global__ __launch_bounds__(128) void ctrlbox_mfma_kernel(BoxArgs a, double* gw
                     const double s11 = Hm[3][3] - fma(Hm[0][3], w01, Hm[1][3] * w11);
                     double c0, c1, c2;                                   // S^-1
                     inv2(s00, s01, s11, c0, c1, c2);
-                    // X = -W S^-1 (upper right), UL = A^-1 - X W'
-                    const double x00 = -fma(w00, c0, w01 * c1), x01 = -fma(w00, c1, w01 * c2);
-                    const double x10 = -fma(w10, c0, w11 * c1), x11 = -fma(w10, c1, w11 * c2);
-                    Hi[0][0] = a0 - fma(x00, w00, x01 * w01);
-                    Hi[0][1] = a1 - fma(x00, w10, x01 * w11);
-                    Hi[1][1] = a2 - fma(x10, w10, x11 * w11);
-                    Hi[1][0] = Hi[0][1];
-                    Hi[0][2] = x00; Hi[0][3] = x01; Hi[1][2] = x10; Hi[1][3] = x11;
-                    Hi[2][0] = x00; Hi[3][0] = x01; Hi[2][1] = x10; Hi[3][1] = x11;
-                    Hi[2][2] = c0; Hi[2][3] = c1; Hi[3][2] = c1; Hi[3][3] = c2;
+                    // the lane's own right-hand side is SOLVED through the blocks -- y2 = S^-1 (r2 - B' A^-1 r1),
+                    // y1 = A^-1 r1 - W y2 -- instead of assembling the 4 x 4 inverse and multiplying: 16 operations after
+                    // S^-1 where the inverse took 17 and its application 16
+                    const double t0 = fma(a0, rhs[0], a1 * rhs[1]), t1 = fma(a1, rhs[0], a2 * rhs[1]);
+                    const double q0 = rhs[2] - fma(Hm[0][2], t0, Hm[1][2] * t1);
+                    const double q1 = rhs[3] - fma(Hm[0][3], t0, Hm[1][3] * t1);
+                    y[2] = fma(c0, q0, c1 * q1);
+                    y[3] = fma(c1, q0, c2 * q1);
+                    y[0] = t0 - fma(w00, y[2], w01 * y[3]);
+                    y[1] = t1 - fma(w10, y[2], w11 * y[3]);
                 }
                 if (!spd && bad == 0) bad = t + 1;
-                const double hsel = col == NS ? 1.0 : 0.0;
-                double rhs[M];
-    #pragma unroll
-                for (int i = 0; i < M; ++i) {
-                    // right-hand side of the free rows: Theta_f,col + (homogeneous column) sum_p H_fp b_p
-                    rhs[i] = gc[i];
-                }
-                if (pins) {
+                if constexpr (M != 4) {
     #pragma unroll
                     for (int i = 0; i < M; ++i) {
-                        double hb0 = 0.0, hb1 = 0.0;
+                        double y0 = 0.0, y1 = 0.0;
     #pragma unroll
                         for (int l = 0; l < M; ++l) {
-                            if (l & 1) hb1 = fma(H[i][l], bz[l], hb1);
-                            else hb0 = fma(H[i][l], bz[l], hb0);
+                            if (l & 1) y1 = fma(Hi[i][l], rhs[l], y1);
+                            else y0 = fma(Hi[i][l], rhs[l], y0);
                         }
-                        rhs[i] = fma(hsel, hb0 + hb1, gc[i]) * mf[i];
+                        y[i] = y0 + y1;
                     }
-                }
-    #pragma unroll
-                for (int i = 0; i < M; ++i) {
-                    double y0 = 0.0, y1 = 0.0;
-    #pragma unroll
-                    for (int l = 0; l < M; ++l) {
-                        if (l & 1) y1 = fma(Hi[i][l], rhs[l], y1);
-                        else y0 = fma(Hi[i][l], rhs[l], y0);
-                    }
-                    y[i] = y0 + y1;
                 }
                 // K~[rg][col] in B-operand layout (= K~' in A-operand layout): free rows -y, pinned rows b e_h'
                 // (y = 0 on a pinned row, bz = 0 on a free one)
