@@ -489,23 +489,55 @@ __device__ __forceinline__ void riccati_backward_mfma(const RiccatiArgs& a, int 
         }
         P[r] = v;
     }
-    auto load_step = [&](int t, v4d& Ab, v4d& Bb, double& Ba) {
+    // Which array (and where) each of this lane's nine operand elements comes from is fixed: resolved ONCE into
+    // (pointer, stride per time step, constant, is-a-load), so that a step's loads are nine unconditional global loads
+    // (an element that is a constant reads a.ct[0] and discards it) and its Q~ column two plain LDS reads -- the
+    // per-element branches this replaces (exec-mask regions, each with its own wait) were a third of the step.
+    typedef const __attribute__((address_space(1))) double* gptr;
+    gptr lp[9];
+    int lstr[9];
+    double lc[9];
+    bool lld[9];
+    {
+        const gptr gA = (gptr)a.At, gB = (gptr)a.Bt, gc_ = (gptr)a.ct;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) { lp[e] = gc_; lstr[e] = 0; lc[e] = 0.0; lld[e] = false; }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = rg + 4 * r;
-            double va = 0.0, vb = 0.0;
             if (row < N) {
-                if (col < N) va = a.At[((size_t)t * N + row) * N + col];
-                else if (col == N) va = a.ct[(size_t)t * N + row];
-                if (col < M) vb = a.Bt[((size_t)t * N + row) * M + col];
+                if (col < N) { lp[r] = gA + row * N + col; lstr[r] = N * N; lld[r] = true; }
+                else if (col == N) { lp[r] = gc_ + row; lstr[r] = N; lld[r] = true; }
+                if (col < M) { lp[4 + r] = gB + row * M + col; lstr[4 + r] = N * M; lld[4 + r] = true; }
             } else if (row == N && col == N) {
-                va = 1.0;
+                lc[r] = 1.0;
             }
-            Ab[r] = va;
-            Bb[r] = vb;
         }
-        Ba = (col < N && rg < M) ? a.Bt[((size_t)t * N + col) * M + rg] : 0.0;
+        if (col < N && rg < M) { lp[8] = gB + col * M + rg; lstr[8] = N * M; lld[8] = true; }
+    }
+    auto load_step = [&](int t, v4d& Ab, v4d& Bb, double& Ba) {
+        double v[9];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) v[e] = lp[e][(long)t * lstr[e]];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Ab[r] = lld[r] ? v[r] : lc[r];
+            Bb[r] = lld[4 + r] ? v[4 + r] : 0.0;
+        }
+        Ba = lld[8] ? v[8] : 0.0;
     };
+    // the -Q xd_t entries of the stage-cost tile: element (row < N, col N) and its mirror
+    int qidx[4];
+    bool qhas[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = rg + 4 * r;
+        qhas[r] = (col == N && row < N) || (row == N && col < N);
+        qidx[r] = qhas[r] ? (col == N ? row : col) : 0;
+    }
+    // where this lane's gain element goes: K[t][rg][col], k[t][rg] (col == N), or nowhere
+    double* kst = (rg < M && col < N) ? a.K + rg * N + col : ((rg < M && col == N) ? a.k + rg : nullptr);
+    const int kstr = (rg < M && col < N) ? M * N : M;
     v4d An, Bn;
     double Ban;
     load_step(T - 1, An, Bn, Ban);
@@ -516,12 +548,11 @@ __device__ __forceinline__ void riccati_backward_mfma(const RiccatiArgs& a, int 
         const v4d Ab = An, Bb = Bn;
         const double Ba = Ban;
         load_step(t > 0 ? t - 1 : 0, An, Bn, Ban);   // prefetch
-        v4d Qt = Qc;
+        v4d Qt;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = rg + 4 * r;
-            if (col == N && row < N) Qt[r] = -qx[t * N + row];
-            else if (row == N && col < N) Qt[r] = -qx[t * N + col];
+            const double qv = qx[t * N + qidx[r]];
+            Qt[r] = qhas[r] ? -qv : Qc[r];
         }
         // D1 = P~ A~ , D2 = P~ B~
         v4d D1 = {0, 0, 0, 0}, D2 = {0, 0, 0, 0};
@@ -580,10 +611,7 @@ __device__ __forceinline__ void riccati_backward_mfma(const RiccatiArgs& a, int 
 #pragma unroll
         for (int i = 0; i < M; ++i) Kb = (i == rg) ? -y[i] : Kb;
         if (rg >= M || col > N) Kb = 0.0;
-        if (rg < M) {
-            if (col < N) a.K[((size_t)t * M + rg) * N + col] = Kb;
-            else if (col == N) a.k[(size_t)t * M + rg] = Kb;
-        }
+        if (kst != nullptr) kst[(size_t)t * kstr] = Kb;
         // A~cl = A~ + B~ K~ ; W = P~ A~cl ; Joseph form  P~ <- Q~_t + K~'(aR)K~ + A~cl' W.
         // (The plain form Q~ + A~'W uses the open-loop A~ on one side: the antisymmetric
         // rounding error of P~ -- which the transposed-operand trick turns into a sign flip --
