@@ -454,6 +454,14 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
     return __hiloint2double(hi, lo);
 }
 
+// -DIRS_RIC_STAMPS (tuning builds only): s_memtime totals per phase of the matrix-core recursion
+#ifdef IRS_RIC_STAMPS
+__device__ long long ric_stamps[8];
+#define RIC_MARK(k) do { const long long n_ = __builtin_amdgcn_s_memtime(); rs_[k] += n_ - rm_; rm_ = n_; } while (0)
+#else
+#define RIC_MARK(k) do {} while (0)
+#endif
+
 template <int N, int M>
 __device__ __forceinline__ void riccati_backward_mfma(const RiccatiArgs& a, int lane, double* qx) {
     static_assert(N + 1 <= 16 && M <= 4, "one 16x16 tile, gains in accumulator register 0");
@@ -515,10 +523,13 @@ __device__ __forceinline__ void riccati_backward_mfma(const RiccatiArgs& a, int 
         }
         if (col < N && rg < M) { lp[8] = gB + col * M + rg; lstr[8] = N * M; lld[8] = true; }
     }
-    auto load_step = [&](int t, v4d& Ab, v4d& Bb, double& Ba) {
-        double v[9];
+    // raw loads now, selection (load or constant) at the point of use one step later: a select right behind its load
+    // would park the wave on the load's latency at the top of every step
+    auto load_raw = [&](int t, double* v) {
 #pragma unroll
         for (int e = 0; e < 9; ++e) v[e] = lp[e][(long)t * lstr[e]];
+    };
+    auto finish_raw = [&](const double* v, v4d& Ab, v4d& Bb, double& Ba) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             Ab[r] = lld[r] ? v[r] : lc[r];
@@ -538,16 +549,27 @@ __device__ __forceinline__ void riccati_backward_mfma(const RiccatiArgs& a, int 
     // where this lane's gain element goes: K[t][rg][col], k[t][rg] (col == N), or nowhere
     double* kst = (rg < M && col < N) ? a.K + rg * N + col : ((rg < M && col == N) ? a.k + rg : nullptr);
     const int kstr = (rg < M && col < N) ? M * N : M;
-    v4d An, Bn;
-    double Ban;
-    load_step(T - 1, An, Bn, Ban);
+    double rawn[9];
+    load_raw(T - 1, rawn);
     wave_sync();                                     // qx visible
     bool ok = true;
     int bad_t = 0;
+#ifdef IRS_RIC_STAMPS
+    long long rs_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rm_ = __builtin_amdgcn_s_memtime();
+#endif
     for (int t = T - 1; t >= 0; --t) {
-        const v4d Ab = An, Bb = Bn;
-        const double Ba = Ban;
-        load_step(t > 0 ? t - 1 : 0, An, Bn, Ban);   // prefetch
+#ifdef IRS_RIC_STAMPS
+        {   // how long the step waits for its prefetched operands
+            const long long w0 = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            rs_[5] += __builtin_amdgcn_s_memtime() - w0;
+            rm_ = __builtin_amdgcn_s_memtime();
+        }
+#endif
+        v4d Ab, Bb;
+        double Ba;
+        finish_raw(rawn, Ab, Bb, Ba);
+        load_raw(t > 0 ? t - 1 : 0, rawn);           // prefetch
         v4d Qt;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -568,6 +590,8 @@ __device__ __forceinline__ void riccati_backward_mfma(const RiccatiArgs& a, int 
             G = __builtin_amdgcn_mfma_f64_16x16x4f64(Bb[s], D1[s], G, 0, 0, 0);
             Hh = __builtin_amdgcn_mfma_f64_16x16x4f64(Bb[s], D2[s], Hh, 0, 0, 0);
         }
+        asm volatile("" :: "v"(G[0]), "v"(Hh[0]));
+        RIC_MARK(0);                                  // head: Q column, prefetch issue, 14 products
         // M x M Hessian to every lane (element (i,j) sits in register 0 of lane 16 i + j)
         double H[M][M];
 #pragma unroll
@@ -591,6 +615,8 @@ __device__ __forceinline__ void riccati_backward_mfma(const RiccatiArgs& a, int 
                 Lm[i][j] = s * Dinv[j];
             }
         }
+        asm volatile("" :: "v"(Dinv[0]), "v"(Dinv[M - 1]));
+        RIC_MARK(1);                                  // gather of H, LDL'
         // this lane's column of G~ (its M entries live in lanes 16 i + col), solve, keep row rg
         double y[M];
 #pragma unroll
@@ -612,6 +638,8 @@ __device__ __forceinline__ void riccati_backward_mfma(const RiccatiArgs& a, int 
         for (int i = 0; i < M; ++i) Kb = (i == rg) ? -y[i] : Kb;
         if (rg >= M || col > N) Kb = 0.0;
         if (kst != nullptr) kst[(size_t)t * kstr] = Kb;
+        asm volatile("" :: "v"(Kb));
+        RIC_MARK(2);                                  // column gather, substitutions, gain, store
         // A~cl = A~ + B~ K~ ; W = P~ A~cl ; Joseph form  P~ <- Q~_t + K~'(aR)K~ + A~cl' W.
         // (The plain form Q~ + A~'W uses the open-loop A~ on one side: the antisymmetric
         // rounding error of P~ -- which the transposed-operand trick turns into a sign flip --
@@ -633,7 +661,15 @@ __device__ __forceinline__ void riccati_backward_mfma(const RiccatiArgs& a, int 
 #pragma unroll
         for (int s = 0; s < KA; ++s) Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(Acl[s], W[s], Pn, 0, 0, 0);
         P = Pn;
+        asm volatile("" :: "v"(P[0]));
+        RIC_MARK(3);                                  // closed loop, W, Joseph form: 10 products
     }
+#ifdef IRS_RIC_STAMPS
+    if (lane == 0) {
+        for (int k_ = 0; k_ < 6; ++k_) ric_stamps[k_] = rs_[k_];
+        ric_stamps[4] = T;
+    }
+#endif
     if (lane == 0) a.info[0] = bad_t;
 }
 
@@ -1325,3 +1361,13 @@ int irs_tvlqr_descent_row(int model, const double* params, int n_params, int T, 
     IRS_CHECK_LAUNCH();
     return IRS_OK;
 }
+
+#ifdef IRS_RIC_STAMPS
+extern "C" void irs_debug_riccati_stamps(void) {
+    long long h[8];
+    (void)hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(ric_stamps), sizeof(h)) != hipSuccess) return;
+    fprintf(stderr, "[riccati stamps] T=%lld  per step: head+14 MFMA %lld, H gather + LDL' %lld, column + substitutions + gain %lld, "
+                    "10 MFMA tail %lld, waiting for the prefetched operands %lld cycles\n", h[4], h[0] / h[4], h[1] / h[4], h[2] / h[4], h[3] / h[4], h[5] / h[4]);
+}
+#endif
