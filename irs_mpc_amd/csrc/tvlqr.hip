@@ -549,9 +549,13 @@ __device__ __forceinline__ void riccati_backward_mfma(const RiccatiArgs& a, int 
     // where this lane's gain element goes: K[t][rg][col], k[t][rg] (col == N), or nowhere
     double* kst = (rg < M && col < N) ? a.K + rg * N + col : ((rg < M && col == N) ? a.k + rg : nullptr);
     const int kstr = (rg < M && col < N) ? M * N : M;
-    double rawn[9];
+    double rawn[9], qn[4];
     load_raw(T - 1, rawn);
     wave_sync();                                     // qx visible
+    // (the Q xd entries travel with the prefetch too: read one step ahead and carried across the back edge -- read
+    // at the point of use, the compiler turns the selection below into four exec-masked LDS reads, each with its wait)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) qn[r] = qx[(T - 1) * N + qidx[r]];
     bool ok = true;
     int bad_t = 0;
 #ifdef IRS_RIC_STAMPS
@@ -572,10 +576,9 @@ __device__ __forceinline__ void riccati_backward_mfma(const RiccatiArgs& a, int 
         load_raw(t > 0 ? t - 1 : 0, rawn);           // prefetch
         v4d Qt;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double qv = qx[t * N + qidx[r]];
-            Qt[r] = qhas[r] ? -qv : Qc[r];
-        }
+        for (int r = 0; r < 4; ++r) Qt[r] = qhas[r] ? -qn[r] : Qc[r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) qn[r] = qx[(t > 0 ? t - 1 : 0) * N + qidx[r]];
         // D1 = P~ A~ , D2 = P~ B~
         v4d D1 = {0, 0, 0, 0}, D2 = {0, 0, 0, 0};
 #pragma unroll
