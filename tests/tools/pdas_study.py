@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from oracle import irs_oracle as orc  # noqa: E402
 
 
+WINDOW = int(os.environ.get("PDAS_WINDOW", "0"))
 FROZEN_TOTAL = []
 DEVICE_MU = os.environ.get("PDAS_DEVICE_MU", "1") == "1"
 
@@ -126,6 +127,16 @@ def solve(prob, s_start, t0, lo, hi, u, act, W, valid_from, strategy, pdas_iter=
             seen[key] = it
             if mode_add_only and (add_lo.any() or add_hi.any()):
                 rel = np.zeros_like(rel)
+        if WINDOW > 0:
+            # only the changes within WINDOW steps of the earliest one (shorter re-sweeps, possibly more rounds)
+            anyc = (add_lo | add_hi | rel).any(axis=1)
+            if anyc.any():
+                first = int(np.nonzero(anyc)[0].min())
+                keep = np.zeros(a.shape[0], dtype=bool)
+                keep[first:first + WINDOW] = True
+                add_lo = add_lo & keep[:, None]
+                add_hi = add_hi & keep[:, None]
+                rel = rel & keep[:, None]
         new[add_lo] = -1
         new[add_hi] = 1
         new[rel] = 0
