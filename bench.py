@@ -528,6 +528,17 @@ def main():
                 fn()
         for _ in range(warmup):
             fn()
+        # the first event pair of a process is slow (lazy initialisation: ~45 us for the first record, and the launches
+        # behind it issue at half the usual rate; tools/short_run_timing.py): a 20-step region -- the driver's -- would
+        # carry that as +3 us per step.  One throw-away pair, used the way the timed region uses its own, before it.
+        w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        w0.record()
+        fn()
+        w1.record()
+        while not w1.query():
+            pass
+        torch.cuda.synchronize()
+        w0.elapsed_time(w1)
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
