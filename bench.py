@@ -543,8 +543,8 @@ def main():
         barrier()
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record()
+        ev0.record()                    # (the device is idle here: recorded before the host clock starts, it still
+        t0 = time.perf_counter()        # brackets exactly the K steps on the device, and its ~6 us of host time is not theirs)
         for _ in range(steps):
             fn()
         ev1.record()
